@@ -1,0 +1,211 @@
+/*
+ * orbfe.h -- C ABI of the MI355X-native ORB front-end (liborbfe.so).
+ *
+ * This is the drop-in boundary for ONE path of geoeo/ORB_SLAM3_V1.0: the per-frame ORB
+ * extractor + Hamming matchers.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference repo).  Plain pointers and sizes only; no C++/torch types.
+ * The reference-signature C++ wrapper lives in include/orbfe_adaptor.hpp; the binding a
+ * maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Error behaviour: every function returns an orbfe_status (0 == ORBFE_OK); nothing in the
+ * library calls exit()/abort() (the reference does: include/cuda/HelperCuda.h:44-50).
+ * A frame with zero keypoints is NOT an error: n == 0 (the reference returns std::nullopt,
+ * src/ORBextractor.cc:494-496); the adaptor maps it back to nullopt.
+ *
+ * Threading: one handle == one HIP stream == one caller at a time for the extract calls (same
+ * as the reference).  The matcher calls take their own scratch from the
+ * handle and are serialised per handle; use one handle per calling thread.
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_MAX_LEVELS 32
+#define ORBFE_DESC_BYTES 32
+
+typedef enum orbfe_status {
+    ORBFE_OK = 0,
+    ORBFE_ERR_INVALID_ARG = 1,   /* NULL pointer, size out of range, batch > max_batch ... */
+    ORBFE_ERR_UNSUPPORTED = 2,   /* configuration outside what the kernels were built for */
+    ORBFE_ERR_NO_DEVICE = 3,     /* no gfx950 device / HIP runtime failure at create */
+    ORBFE_ERR_HIP = 4,           /* a HIP call failed; see orbfe_last_error() */
+    ORBFE_ERR_OUT_OF_MEMORY = 5,
+    ORBFE_ERR_INTERNAL = 6       /* device-side guard tripped (capacity / round limit) */
+} orbfe_status;
+
+/* Layout-identical to ORB_SLAM3::KeyPoint (include/KeyPoint.h:7-12): 24 bytes, memcpy-able. */
+typedef struct orbfe_keypoint {
+    float x, y;     /* LEVEL pixel coordinates (the reference never rescales, S6) */
+    int response;   /* FAST corner score (src/cuda/Fast_gpu.cu:193-216) */
+    float size;     /* (int)(31 * invScaleFactor[octave]) (src/ORBextractor.cc:511,531) */
+    int octave;
+    float angle;    /* degrees in [0, 360] */
+} orbfe_keypoint;
+
+/* The 8 constructor arguments of ORBextractor::ORBextractor (include/ORBextractor.h:55-56,
+ * src/ORBextractor.cc:82-149) plus placement / batching knobs that have no reference analogue. */
+typedef struct orbfe_params {
+    int n_features;        /* nFeatures      */
+    int n_fast_features;   /* nFastFeatures  (per-level FAST candidate cap) */
+    float scale_factor;    /* scaleFactor    */
+    int n_levels;          /* nlevels        */
+    int ini_th_fast;       /* iniThFAST      */
+    int min_th_fast;       /* minThFAST      */
+    int image_width;       /* imageWidth     */
+    int image_height;      /* imageHeight    */
+    int device_id;         /* HIP device ordinal (0 for one-process-per-GPU) */
+    int max_batch;         /* frames per orbfe_extract_batch* call (>= 1); sizes the workspace */
+} orbfe_params;
+
+typedef struct orbfe_handle orbfe_handle;
+
+/* -------------------------------------------------------------------------------------------
+ * Extractor
+ * ---------------------------------------------------------------------------------------- */
+
+/* replaces ORBextractor::ORBextractor (src/ORBextractor.cc:82-149): scale tables, per-level
+ * feature budget, pyramid + scratch allocation (AllocatePyramid :587-605, GpuFast::GpuFast
+ * src/cuda/Fast_gpu.cu:321-332).  All device memory is allocated here, none per frame. */
+int orbfe_create(const orbfe_params *params, orbfe_handle **out);
+void orbfe_destroy(orbfe_handle *h);
+
+/* replaces GetLevels / GetScaleFactor (include/ORBextractor.h:64-72) */
+int orbfe_get_levels(const orbfe_handle *h);
+float orbfe_get_scale_factor(const orbfe_handle *h);
+/* replaces GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:74-92).  Each array holds n_levels floats;
+ * any pointer may be NULL. */
+int orbfe_get_scale_tables(const orbfe_handle *h, float *scale_factors, float *inv_scale_factors,
+                           float *level_sigma2, float *inv_level_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:112-124) and pyramid level sizes (:594-604) */
+int orbfe_get_level_info(const orbfe_handle *h, int *features_per_level, int *level_width,
+                         int *level_height);
+/* upper bound on keypoints per frame: sum over levels of max(N_level + 3, 4 * nIni).  Output
+ * arrays of the extract calls are sized with this stride. */
+int orbfe_max_keypoints(const orbfe_handle *h);
+
+/* replaces ORBextractor::extractFeatures(const cv::cuda::HostMem&) (include/ORBextractor.h:62,
+ * src/ORBextractor.cc:543-585).  `gray` is a host pointer to an 8-bit image of the size given at
+ * create, `pitch` bytes per row.  kp_out / desc_out hold orbfe_max_keypoints() entries; *n_out
+ * receives the count (0 == the reference's nullopt); per_level_counts (n_levels ints) may be
+ * NULL.  One H2D copy, one D2H copy, one host sync. */
+int orbfe_extract(orbfe_handle *h, const uint8_t *gray, int pitch, orbfe_keypoint *kp_out,
+                  uint8_t *desc_out, int *n_out, int *per_level_counts);
+
+/* Batched many-frame mode (BASELINE config 4; no reference analogue).  Host pointers; frame b's
+ * results start at kp_out + b*cap, desc_out + b*cap*32, per_level_counts + b*n_levels with
+ * cap = orbfe_max_keypoints(). */
+int orbfe_extract_batch(orbfe_handle *h, const uint8_t *const *grays, int pitch, int batch,
+                        orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out,
+                        int *per_level_counts);
+
+/* Same, with everything already resident in HBM: d_gray points at `batch` frames
+ * `frame_stride` bytes apart in device memory; all outputs are device pointers with the strides
+ * above.  Asynchronous on `stream` (a hipStream_t; NULL == the handle's own stream); no host
+ * sync is performed.  This is the entry bench.py times. */
+int orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, size_t frame_stride,
+                               int pitch, int batch, orbfe_keypoint *d_kp_out,
+                               uint8_t *d_desc_out, int *d_n_out, int *d_per_level_counts,
+                               void *stream);
+
+/* replaces the public members mvImagePyramid / mvBlurredImagePyramid
+ * (include/ORBextractor.h:94-95): copies level `level` of frame `frame` of the LAST extract call
+ * to host memory (out_pitch bytes per row).  Synchronises. */
+int orbfe_get_pyramid_level(orbfe_handle *h, int frame, int level, int blurred, uint8_t *out,
+                            int out_pitch);
+
+/* Diagnostics for parity tests: FAST candidates of (frame, level) of the last extract call as
+ * packed words (score << 24 | y << 12 | x), unordered; counters[4] = {survivors(low pass),
+ * survivors with score >= iniThFAST, pre-NMS corners >= minThFAST, pre-NMS corners >= iniThFAST}.
+ * Returns the number of words written (<= cap) through *n_out. */
+int orbfe_debug_get_candidates(orbfe_handle *h, int frame, int level, uint32_t *packed, int cap,
+                               int *n_out, int counters[4]);
+
+/* Stage timing (HIP events on the launch stream).  While enabled, every extract call records
+ * one event per stage boundary (a pool of 128 event sets; enabling resets the pool).
+ * orbfe_get_stage_ms() synchronises on the recorded events and returns, per stage in the order of
+ * orbfe_stage_name(), the SUM of elapsed milliseconds over the recorded calls; *n_calls receives
+ * how many calls were summed (<= 128).  The last stage is the whole chain ("total"). */
+#define ORBFE_NUM_STAGES 6
+int orbfe_set_stage_timing(orbfe_handle *h, int enabled);
+int orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_NUM_STAGES], int *n_calls);
+const char *orbfe_stage_name(int stage);
+
+/* -------------------------------------------------------------------------------------------
+ * Matcher
+ * ---------------------------------------------------------------------------------------- */
+
+#define ORBFE_TH_LOW 30        /* ORBmatcher::TH_LOW  (include/ORBmatcher.h:73) */
+#define ORBFE_TH_HIGH 100      /* ORBmatcher::TH_HIGH (:74) */
+#define ORBFE_HISTO_LENGTH 30  /* ORBmatcher::HISTO_LENGTH (:75) */
+
+/* replaces ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1375-1391); host, no GPU. */
+int orbfe_hamming(const uint8_t *a, const uint8_t *b);
+
+/* What SearchByProjection reads from a Frame (include/Frame.h): keypoints, descriptors, the
+ * static grid geometry (src/Frame.cc:101-105) and mvScaleFactors. */
+typedef struct orbfe_frame_view {
+    int n;                        /* mNumKeypoints */
+    const orbfe_keypoint *kp;     /* mvKeysUn */
+    const uint8_t *desc;          /* mDescriptors, n x 32 */
+    int grid_cols, grid_rows;     /* mFrameGridCols / mFrameGridRows */
+    float min_x, min_y;           /* mnMinX / mnMinY */
+    float grid_inv_w, grid_inv_h; /* mfGridElementWidthInv / mfGridElementHeightInv */
+    int n_levels;
+    const float *scale_factors;   /* mvScaleFactors */
+} orbfe_frame_view;
+
+/* The MapPoint fields SearchByProjection reads (src/ORBmatcher.cc:36-59). */
+typedef struct orbfe_map_point {
+    float proj_x, proj_y;  /* mTrackProjX / mTrackProjY */
+    float view_cos;        /* mTrackViewCos */
+    float track_depth;     /* mTrackDepth */
+    int level;             /* mnTrackScaleLevel */
+    int in_view;           /* mbTrackInView */
+    int bad;               /* isBad() */
+    int observations;      /* Observations() */
+} orbfe_map_point;
+
+/* replaces ORBmatcher::SearchByProjection(Frame, vector<MapPoint>, th, bFarPoints, thFarPoints,
+ * nnRatio, checkOrientation) (src/ORBmatcher.cc:31-123; callers src/Tracking.cc:1115), mono.
+ * All pointers are HOST pointers.  init_obs[i] = -1 if F->mvpMapPoints[i] is empty on entry, else
+ * the Observations() of the point it holds (may be NULL == all empty).  match_out[i] = index of
+ * the map point this call writes into F->mvpMapPoints[i], or -1.  *n_matches = return value of
+ * the reference function.  The greedy, order-dependent claim semantics are reproduced exactly. */
+int orbfe_match_projection(orbfe_handle *h, const orbfe_frame_view *frame, int n_map_points,
+                           const orbfe_map_point *map_points, const uint8_t *mp_desc,
+                           const int *init_obs, float th, int far_points, float th_far_points,
+                           float nn_ratio, int *match_out, int *n_matches);
+
+/* replaces ORBmatcher::SearchByBoW(KeyFrame, Frame, matches, nnRatio, checkOrientation)
+ * (src/ORBmatcher.cc:133-327; caller src/Tracking.cc:835), mono.  The merge-walk over the two
+ * DBoW2::FeatureVector maps (:161-163,289-301) is done by the caller/adaptor and handed over as
+ * CSR groups in ascending NodeId order: group g = KF features kf_idx[kf_off[g]..kf_off[g+1]) and
+ * frame features f_idx[f_off[g]..f_off[g+1]).  kf_has_mp[i] != 0 iff KF feature i has a non-bad
+ * map point.  match_out[j] (n_f ints) = KF feature whose map point goes to frame feature j, or
+ * -1; *n_matches = the reference's return value (after the rotation-histogram filter). */
+int orbfe_match_bow(orbfe_handle *h, int n_groups, const int *kf_off, const int *kf_idx,
+                    const int *f_off, const int *f_idx, int n_kf, const uint8_t *kf_desc,
+                    const float *kf_angle, const uint8_t *kf_has_mp, int n_f,
+                    const uint8_t *f_desc, const float *f_angle, float nn_ratio,
+                    int check_orientation, int *match_out, int *n_matches);
+
+/* -------------------------------------------------------------------------------------------
+ * Misc
+ * ---------------------------------------------------------------------------------------- */
+const char *orbfe_status_string(int status);
+/* message of the last failing HIP call on this handle ("" if none) */
+const char *orbfe_last_error(const orbfe_handle *h);
+/* library / build identification, e.g. "orbfe 0.1 gfx950" */
+const char *orbfe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H */

@@ -1,0 +1,267 @@
+/*
+ * match_oracle.c -- CPU ORACLE for the ORBmatcher hot loops.  TEST INFRASTRUCTURE ONLY.
+ * Literal restatement of src/ORBmatcher.cc:31-131 (SearchByProjection, mono), :133-327
+ * (SearchByBoW, mono), :1328-1370 (ComputeThreeMaxima), :1375-1391 (DescriptorDistance) and of
+ * the Frame grid they lean on, src/Frame.cc:145-176 (AssignFeaturesToGrid), :404-468
+ * (GetFeaturesInArea), :470-480 (PosInGrid).
+ */
+#include "orb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TH_LOW 30        /* include/ORBmatcher.h:73 */
+#define TH_HIGH 100      /* :74 */
+#define HISTO_LENGTH 30  /* :75 */
+
+/* DescriptorDistance, src/ORBmatcher.cc:1375-1391 (bit-hack popcount on 8 int32 words) */
+int orc_hamming(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+/* Frame::PosInGrid, src/Frame.cc:470-480 (round(), linear-index-only validation) */
+static int pos_in_grid(const orc_frame_view *F, const orc_keypoint *kp, int *posX, int *posY)
+{
+    *posX = (int)roundf((kp->x - F->minX) * F->gridInvW);
+    *posY = (int)roundf((kp->y - F->minY) * F->gridInvH);
+    int linearIdx = *posY * F->gridCols + *posX;
+    int size = F->gridCols * F->gridRows;
+    return (linearIdx >= 0) & (linearIdx < size);
+}
+
+void orc_assign_grid(const orc_frame_view *F, int *cellOut)
+{
+    for (int i = 0; i < F->n; i++) {
+        int px, py;
+        cellOut[i] = pos_in_grid(F, &F->kp[i], &px, &py) ? py * F->gridCols + px : -1;
+    }
+}
+
+typedef struct {
+    int *idx;
+    int n, cap;
+} cell_t;
+
+static cell_t *build_grid(const orc_frame_view *F)
+{
+    int nCells = F->gridCols * F->gridRows;
+    cell_t *g = (cell_t *)calloc((size_t)nCells, sizeof(cell_t));
+    for (int i = 0; i < F->n; i++) { /* AssignFeaturesToGrid, src/Frame.cc:157-176 */
+        int px, py;
+        if (pos_in_grid(F, &F->kp[i], &px, &py)) {
+            cell_t *c = &g[py * F->gridCols + px];
+            if (c->n == c->cap) {
+                c->cap = c->cap ? 2 * c->cap : 4;
+                c->idx = (int *)realloc(c->idx, sizeof(int) * (size_t)c->cap);
+            }
+            c->idx[c->n++] = i;
+        }
+    }
+    return g;
+}
+
+static void free_grid(const orc_frame_view *F, cell_t *g)
+{
+    int nCells = F->gridCols * F->gridRows;
+    for (int i = 0; i < nCells; i++) free(g[i].idx);
+    free(g);
+}
+
+/* Frame::GetFeaturesInArea, src/Frame.cc:404-468 */
+static int features_in_area(const orc_frame_view *F, const cell_t *g, float x, float y, float r,
+                            int minLevel, int maxLevel, int *out)
+{
+    int n = 0;
+    float factorX = r, factorY = r;
+    int nMinCellX = (int)floorf((x - F->minX - factorX) * F->gridInvW);
+    if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= F->gridCols) return 0;
+    int nMaxCellX = (int)ceilf((x - F->minX + factorX) * F->gridInvW);
+    if (nMaxCellX > F->gridCols - 1) nMaxCellX = F->gridCols - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - F->minY - factorY) * F->gridInvH);
+    if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= F->gridRows) return 0;
+    int nMaxCellY = (int)ceilf((y - F->minY + factorY) * F->gridInvH);
+    if (nMaxCellY > F->gridRows - 1) nMaxCellY = F->gridRows - 1;
+    if (nMaxCellY < 0) return 0;
+
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const cell_t *c = &g[iy * F->gridCols + ix];
+            for (int j = 0; j < c->n; j++) {
+                const orc_keypoint *kpUn = &F->kp[c->idx[j]];
+                if (bCheckLevels) {
+                    if (kpUn->octave < minLevel || (maxLevel >= 0 && kpUn->octave > maxLevel)) continue;
+                }
+                const float distx = kpUn->x - x;
+                const float disty = kpUn->y - y;
+                if (fabsf(distx) < factorX && fabsf(disty) < factorY) out[n++] = c->idx[j];
+            }
+        }
+    return n;
+}
+
+/* RadiusByViewingCos, src/ORBmatcher.cc:125-131 */
+static float radius_by_viewing_cos(float viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }
+
+int orc_search_by_projection(const orc_frame_view *F, int M, const orc_map_point *mps,
+                             const uint8_t *mpDesc, const int *initObs, float th, int bFarPoints,
+                             float thFarPoints, float nnRatio, int *matchOut)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0;
+    cell_t *g = build_grid(F);
+    int *vIndices = (int *)malloc(sizeof(int) * (size_t)(F->n > 0 ? F->n : 1));
+    /* slotObs[i]: Observations() of the map point currently in F->mvpMapPoints[i], -1 if none */
+    int *slotObs = (int *)malloc(sizeof(int) * (size_t)(F->n > 0 ? F->n : 1));
+    for (int i = 0; i < F->n; i++) {
+        slotObs[i] = initObs ? initObs[i] : -1;
+        matchOut[i] = -1;
+    }
+    for (int iMP = 0; iMP < M; iMP++) {
+        const orc_map_point *pMP = &mps[iMP];
+        if (!pMP->inView) continue;                                   /* :40-41 (no right view in mono) */
+        if (bFarPoints && pMP->trackDepth > thFarPoints) continue;    /* :43-44 */
+        if (pMP->bad) continue;                                       /* :46-47 */
+        const int nPredictedLevel = pMP->level;
+        float r = radius_by_viewing_cos(pMP->viewCos);
+        if (bFactor) r *= th;
+        r *= F->scaleFactors[nPredictedLevel];
+        int nI = features_in_area(F, g, pMP->projX, pMP->projY, r, nPredictedLevel - 1, nPredictedLevel, vIndices);
+        if (nI == 0) continue;
+        const uint8_t *MPdescriptor = mpDesc + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nI; k++) {
+            const int idx = vIndices[k];
+            if (slotObs[idx] > 0) continue;                           /* :77-79 */
+            /* :81-86 stereo check is inert in mono (mvuRight < 0) */
+            const int dist = orc_hamming(MPdescriptor, F->desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = F->kp[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F->kp[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {                                    /* :108-117 */
+            if (bestLevel == bestLevel2 && (float)bestDist > nnRatio * (float)bestDist2) continue;
+            if (bestLevel != bestLevel2 || (float)bestDist <= nnRatio * (float)bestDist2) {
+                matchOut[bestIdx] = iMP;
+                slotObs[bestIdx] = pMP->observations;
+                nmatches++;
+            }
+        }
+    }
+    free(vIndices);
+    free(slotObs);
+    free_grid(F, g);
+    return nmatches;
+}
+
+/* ComputeThreeMaxima, src/ORBmatcher.cc:1328-1370 */
+static void compute_three_maxima(const int *histoSize, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histoSize[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            *ind3 = *ind2; *ind2 = *ind1; *ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            *ind3 = *ind2; *ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            *ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        *ind2 = -1;
+        *ind3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        *ind3 = -1;
+    }
+}
+
+int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx,
+                      int nKF, const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfHasMP,
+                      int nF, const uint8_t *fDesc, const float *fAngle, float nnRatio,
+                      int checkOrientation, int *matchOut)
+{
+    (void)nKF;
+    int nmatches = 0;
+    for (int i = 0; i < nF; i++) matchOut[i] = -1;
+    int *rotHist[HISTO_LENGTH];
+    int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(nF > 0 ? nF : 1));
+        rotN[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+
+    for (int g = 0; g < G; g++) { /* one shared vocabulary node, :161-287 */
+        for (int iKF = kfOff[g]; iKF < kfOff[g + 1]; iKF++) {
+            const int realIdxKF = kfIdx[iKF];
+            if (!kfHasMP[realIdxKF]) continue;                 /* :172-176 */
+            const uint8_t *dKF = kfDesc + (size_t)realIdxKF * 32;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int iF = fOff[g]; iF < fOff[g + 1]; iF++) {
+                const int realIdxF = fIdx[iF];
+                if (matchOut[realIdxF] >= 0) continue;         /* :188-189 */
+                const int dist = orc_hamming(dKF, fDesc + (size_t)realIdxF * 32);
+                if (dist < bestDist1) {
+                    bestDist2 = bestDist1;
+                    bestDist1 = dist;
+                    bestIdxF = realIdxF;
+                } else if (dist < bestDist2) {
+                    bestDist2 = dist;
+                }
+            }
+            if (bestDist1 <= TH_LOW) {                          /* :237 */
+                if ((float)bestDist1 < nnRatio * (float)bestDist2) {
+                    matchOut[bestIdxF] = realIdxKF;
+                    if (checkOrientation) {
+                        float rot = kfAngle[realIdxKF] - fAngle[bestIdxF];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin][rotN[bin]++] = bestIdxF;
+                    }
+                    nmatches++;
+                }
+                /* :263-286 right-image branch never fires in mono (bestDist1R stays 256) */
+            }
+        }
+    }
+    if (checkOrientation) { /* :304-322 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) {
+                matchOut[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    return nmatches;
+}

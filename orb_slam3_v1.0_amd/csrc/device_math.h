@@ -1,0 +1,94 @@
+// device_math.h -- the pinned fp32 sequences of SPEC DECISION S5 for gfx950.
+// Replaces atan2f (src/cuda/Angle_gpu.cu:73) and cosf/sinf (src/cuda/Orb_gpu.cu:329) of the
+// reference, whose last bits depend on the CUDA math library.  Every operation is a single
+// IEEE-754 fp32 op; the translation unit is compiled with -ffp-contract=off so no FMA is formed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#pragma clang fp contract(off)
+
+namespace orbfe {
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    // BORDER_REFLECT_101 for any offset (period 2n-2); n >= 2 on every pyramid level
+    const int p = 2 * n - 2;
+    i = i % p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
+
+__device__ __forceinline__ float spec_atan2f(float y, float x)
+{
+    const float kPi = 0x1.921fb6p+1f, kPi2 = 0x1.921fb6p+0f, kPi4 = 0x1.921fb6p-1f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay;
+    const float mn = ax > ay ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float t = mn / mx;  // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+    float base = 0.0f;
+    if (t > 0x1.a8279ap-2f) {
+        t = (t - 1.0f) / (t + 1.0f);
+        base = kPi4;
+    }
+    const float z = t * t;
+    float p = 0x1.61e174p-4f * z;
+    p = p + -0x1.1fe904p-3f;
+    p = p * z;
+    p = p + 0x1.99799ep-3f;
+    p = p * z;
+    p = p + -0x1.555556p-2f;
+    float r = p * z;
+    r = r * t;
+    r = r + t;
+    r = base + r;
+    if (ay > ax) r = kPi2 - r;
+    if (x < 0.0f) r = kPi - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+// src/cuda/Angle_gpu.cu:73-75
+__device__ __forceinline__ float atan2_deg(float m01, float m10)
+{
+    const float kPi = 0x1.921fb6p+1f;
+    float d = spec_atan2f(m01, m10);
+    if (d < 0.0f) d = d + 2.0f * kPi;
+    d = d * (180.0f / kPi);
+    return d;
+}
+
+// cos/sin of an angle given in degrees (src/cuda/Orb_gpu.cu:327-329)
+__device__ __forceinline__ void cos_sin_deg(float deg, float& c, float& s)
+{
+    float kf = deg * 0x1.6c16c2p-7f;
+    kf = kf + 0.5f;
+    const int k = (int)kf;
+    const float r = deg - 90.0f * (float)k;
+    const float x = r * 0x1.1df46ap-6f;
+    const float z = x * x;
+    float p = -0x1.9b7856p-13f * z;
+    p = p + 0x1.110e32p-7f;
+    p = p * z;
+    p = p + -0x1.555558p-3f;
+    float sn = p * z;
+    sn = sn * x;
+    sn = sn + x;
+    float q = 0x1.9bfe2ep-16f * z;
+    q = q + -0x1.6c134p-10f;
+    q = q * z;
+    q = q + 0x1.555554p-5f;
+    float cs = q * z;
+    cs = cs * z;
+    float h = 0.5f * z;
+    h = 1.0f - h;
+    cs = cs + h;
+    switch (k & 3) {
+    case 0: c = cs; s = sn; break;
+    case 1: c = -sn; s = cs; break;
+    case 2: c = -cs; s = -sn; break;
+    default: c = sn; s = -cs; break;
+    }
+}
+
+}  // namespace orbfe

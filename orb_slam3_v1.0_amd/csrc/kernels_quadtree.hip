@@ -1,0 +1,427 @@
+// kernels_quadtree.hip -- DistributeOctTree + best-per-node on gfx950, one workgroup per
+// (frame, level), bit-exact against the sequential std::list algorithm of the reference.
+//
+// Replaces ORBextractor::DistributeOctTree (src/ORBextractor.cc:226-431), ExtractorNode::DivideNode
+// (:151-207), compareNodes (:209-224), the two-threshold bookkeeping of ComputeKeyPointsOctTree
+// (:449-482) and the best-response-per-node loop (:505-527), all of which run on the CPU in the
+// reference.
+//
+// How the list choreography becomes data-parallel:
+//  * The node list is kept as an ARRAY in list order (index 0 == list head).  A pass that splits
+//    the nodes e_0..e_{J-1} (in processing order) and push_front()s their non-empty children
+//    n1..n4 produces   new list = reverse(flatmap(e_r -> children ascending)) ++ (old list minus
+//    the split nodes, order kept).  Positions follow from two prefix sums.
+//  * Uniform phase (:283-361): processing order == list order, every node with > 1 point splits.
+//  * Sorted phase (:362-427): processing order == descending (count, UL.x, UL.y, creation seq)
+//    (S4 total order); the mid-pass early break (:419-420) is the first r whose running size
+//    n + sum(children-1) reaches N (children-1 >= 0, so the running size is monotone).
+//  * Points never move: each candidate carries the index of its node (u16 in HBM scratch) and is
+//    re-labelled once per round; per-child counts are integer LDS atomics (order-independent).
+//  * The reference feeds the tree the concatenation [high-threshold list, low-threshold list], so
+//    a strong corner appears twice.  Duplicates only ever act through vKeys.size(): a candidate
+//    gets weight (score >= iniTh) + (retry pass taken && inside the low-list cap).
+//  * Best point per node: max response, ties -> first in vKeys order == smallest raster key.
+#include "launch.h"
+
+namespace orbfe {
+
+constexpr int kQtThreads = 512;
+constexpr int kQtMaxRounds = 48;
+constexpr uint32_t kKeyInf = 0x01000000u;  // larger than any raster key
+
+struct Box {
+    int16_t ulx, urx, uly, bry;
+};
+
+__device__ __forceinline__ int child_code(const Box& b, int x, int y)
+{
+    const int halfX = (b.urx - b.ulx + 1) >> 1;  // ceil(float(UR.x-UL.x)/2), :153
+    const int halfY = (b.bry - b.uly + 1) >> 1;  // :154
+    const int right = !(x < b.ulx + halfX);      // kp.pt.x < n1.UR.x, :188
+    const int bottom = !(y < b.uly + halfY);     // kp.pt.y < n1.BR.y, :190
+    return right + 2 * bottom;                   // n1=0 n2=1 n3=2 n4=3
+}
+
+__device__ __forceinline__ Box child_box(const Box& b, int c)
+{
+    const int halfX = (b.urx - b.ulx + 1) >> 1;
+    const int halfY = (b.bry - b.uly + 1) >> 1;
+    Box r;
+    r.ulx = (c & 1) ? (int16_t)(b.ulx + halfX) : b.ulx;
+    r.urx = (c & 1) ? b.urx : (int16_t)(b.ulx + halfX);
+    r.uly = (c & 2) ? (int16_t)(b.uly + halfY) : b.uly;
+    r.bry = (c & 2) ? b.bry : (int16_t)(b.uly + halfY);
+    return r;
+}
+
+// exclusive scan of one int per thread across the block (tid order); all threads must call.
+__device__ __forceinline__ int block_excl_scan(int v, int& total, int* sWave)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();  // protect sWave from the previous use
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kQtThreads / 64; i++) {
+        const int s = sWave[i];
+        if (i < wave) base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + incl - v;
+}
+
+template <int NC>
+__global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc* __restrict__ P,
+                                                             const uint32_t* __restrict__ cand,
+                                                             uint16_t* __restrict__ nodeOfAll,
+                                                             uint32_t* __restrict__ counters,
+                                                             uint32_t* __restrict__ lvlKp)
+{
+    constexpr int IPT = NC / kQtThreads;  // nodes per thread in node-parallel steps
+    static_assert(NC % kQtThreads == 0, "NC must be a multiple of the block size");
+
+    __shared__ Box sBox[2][NC];
+    __shared__ int sCnt[2][NC];
+    __shared__ int sCC[NC * 4];       // child counts, then child new positions
+    __shared__ int sKeep[NC];         // new position of a non-split node
+    __shared__ int sS[NC];            // flat-map offset of a split node's first child
+    __shared__ uint8_t sSplit[NC];
+    __shared__ uint8_t sNch[NC];
+    __shared__ unsigned long long sKey[NC];
+    __shared__ int sProc[NC];         // sorted phase: rank -> node
+    __shared__ int sWave[kQtThreads / 64];
+    __shared__ int sRed[4];
+
+    const int f = blockIdx.x, l = blockIdx.y;
+    const int nL = P->nLevels;
+    const LevelDesc& L = P->lv[l];
+    const int tid = threadIdx.x;
+    uint32_t* cnt = counters + ((size_t)f * nL + l) * kCntWords;
+    const uint32_t* C = cand + L.candOff + (size_t)f * L.candCap;
+    uint16_t* nodeOf = nodeOfAll + L.candOff + (size_t)f * L.candCap;
+    uint32_t* out = lvlKp + (size_t)f * P->kpCapFrame + L.kpBase;
+
+    const int N = L.nFeatures;
+    const int nFast = P->nFast;
+    const int iniTh = P->iniTh;
+    int cL = (int)min(cnt[kCntCand], (uint32_t)L.candCap);
+    const int cH = (int)cnt[kCntHigh];
+    // retry rule, src/ORBextractor.cc:440,463-465 (unsigned diff, double compare)
+    const unsigned diff = (unsigned)nFast - (unsigned)cH;
+    const bool retry = (double)diff > 0.25 * (double)nFast;
+    uint32_t keyCut = kKeyInf;
+    int lowKept = 0;
+    if (retry && cL > 0) {
+        lowKept = cL;
+        if (cH + cL > nFast) lowKept = max(nFast - cH, 0);  // :470-473, raster-first entries survive (S2b)
+    }
+    if (retry && lowKept < cL) {
+        // rare path: smallest key K with #{key < K} >= lowKept  (binary search over the 24-bit key)
+        uint32_t lo = 0, hi = kKeyInf;  // invariant: count(key < lo) < lowKept+? ; find min K: count(key<K) >= lowKept
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            int c = 0;
+            for (int p = tid; p < cL; p += kQtThreads) c += cand_key(C[p]) < mid;
+            int tot;
+            block_excl_scan(c, tot, sWave);
+            if (tot >= lowKept) hi = mid; else lo = mid + 1;
+        }
+        keyCut = lo;
+    }
+    const int totalPts = cH + lowKept;
+    if (totalPts == 0) {
+        if (tid == 0) cnt[kCntKp] = 0;
+        return;
+    }
+    if (L.nodeCap > NC) {  // host picks NC >= nodeCap; guard anyway
+        if (tid == 0) { cnt[kCntKp] = 0; atomicOr(&cnt[kCntStatus], (uint32_t)kFlagNodeOverflow); }
+        return;
+    }
+
+#define PT_WEIGHT(cw) ((int)(cand_score(cw) >= iniTh) + (int)(retry && cand_key(cw) < keyCut))
+
+    // ---- initial nodes, :231-274 ----
+    const int nIni = L.nIni;
+    const float hX = L.hX;
+    for (int i = tid; i < NC; i += kQtThreads) sCnt[0][i] = 0;
+    __syncthreads();
+    for (int p = tid; p < cL; p += kQtThreads) {
+        const uint32_t cw = C[p];
+        const int wgt = PT_WEIGHT(cw);
+        if (wgt) atomicAdd(&sCnt[0][(int)((float)cand_x(cw) / hX)], wgt);
+    }
+    __syncthreads();
+    // compact away empty initial nodes (nIni is tiny: serial on one thread)
+    if (tid == 0) {
+        int n = 0;
+        for (int i = 0; i < nIni; i++) {
+            const int c = sCnt[0][i];
+            sKeep[i] = n;
+            if (c > 0) {
+                Box b;
+                b.ulx = (int16_t)(int)(hX * (float)i);
+                b.urx = (int16_t)(int)(hX * (float)(i + 1));
+                b.uly = 0;
+                b.bry = (int16_t)L.h;
+                sBox[1][n] = b;
+                sCnt[1][n] = c;
+                n++;
+            }
+        }
+        sRed[0] = n;
+    }
+    __syncthreads();
+    int n = sRed[0];
+    for (int p = tid; p < cL; p += kQtThreads) {
+        const uint32_t cw = C[p];
+        if (PT_WEIGHT(cw)) nodeOf[p] = (uint16_t)sKeep[(int)((float)cand_x(cw) / hX)];
+    }
+    int cur = 1;  // buffer holding the current list
+    bool sortedMode = false;
+    bool overflow = false;
+
+    for (int round = 0; round < kQtMaxRounds; round++) {
+        const int prevSize = n;
+        Box* box = sBox[cur];
+        int* ncnt = sCnt[cur];
+        Box* nbox = sBox[cur ^ 1];
+        int* nncnt = sCnt[cur ^ 1];
+
+        // 1. child counts
+        for (int i = tid; i < n * 4; i += kQtThreads) sCC[i] = 0;
+        __syncthreads();
+        for (int p = tid; p < cL; p += kQtThreads) {
+            const uint32_t cw = C[p];
+            const int wgt = PT_WEIGHT(cw);
+            if (wgt) {
+                const int i = nodeOf[p];
+                if (ncnt[i] > 1) atomicAdd(&sCC[4 * i + child_code(box[i], cand_x(cw), cand_y(cw))], wgt);
+            }
+        }
+        __syncthreads();
+
+        // 2. per node: expandable, number of non-empty children
+        int myExp[IPT], myNch[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const int i = tid * IPT + k;
+            int e = 0, nc = 0;
+            if (i < n && ncnt[i] > 1) {
+                e = 1;
+                nc = (sCC[4 * i] > 0) + (sCC[4 * i + 1] > 0) + (sCC[4 * i + 2] > 0) + (sCC[4 * i + 3] > 0);
+            }
+            myExp[k] = e;
+            myNch[k] = nc;
+            if (i < NC) { sNch[i] = (uint8_t)nc; sSplit[i] = 0; }
+        }
+
+        int T = 0;  // total children created this round
+        if (!sortedMode) {
+            // 3a. uniform: every expandable node splits, processing order == list order
+            int loc = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) loc += myNch[k];
+            int base = block_excl_scan(loc, T, sWave);
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int i = tid * IPT + k;
+                if (i < n) {
+                    sS[i] = base;
+                    sSplit[i] = (uint8_t)myExp[k];
+                }
+                base += myNch[k];
+            }
+        } else {
+            // 3b. sorted: rank expandable nodes by descending (count, UL.x, UL.y, creation seq)
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int i = tid * IPT + k;
+                if (i < n) {
+                    unsigned long long key = 0;
+                    if (myExp[k])
+                        key = ((unsigned long long)(uint32_t)ncnt[i] << 40) |
+                              ((unsigned long long)(uint16_t)box[i].ulx << 28) |
+                              ((unsigned long long)(uint16_t)box[i].uly << 16) |
+                              (unsigned long long)(0xFFFFu - (uint32_t)i);
+                    sKey[i] = key;  // 0 == not expandable (any real key is > 0)
+                }
+            }
+            __syncthreads();
+            int locM = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) locM += myExp[k];
+            int m;
+            block_excl_scan(locM, m, sWave);
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int i = tid * IPT + k;
+                if (i < n && myExp[k]) {
+                    const unsigned long long key = sKey[i];
+                    int r = 0;
+                    for (int j = 0; j < n; j++) r += sKey[j] > key;
+                    sProc[r] = i;
+                }
+            }
+            __syncthreads();
+            // running size after processing rank r: n + sum_{q<=r} (nch-1); J = first r reaching N
+            int locInc[IPT], locSum = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int r = tid * IPT + k;
+                locInc[k] = (r < m) ? (int)sNch[sProc[r]] - 1 : 0;
+                locSum += locInc[k];
+            }
+            int totInc;
+            int run = block_excl_scan(locSum, totInc, sWave);
+            int myJ = m;  // candidate: first rank where the inclusive running size >= N
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int r = tid * IPT + k;
+                run += locInc[k];
+                if (r < m && n + run >= N && myJ == m) myJ = r + 1;
+            }
+            if (tid == 0) sRed[1] = m;
+            __syncthreads();
+            if (myJ < m) atomicMin(&sRed[1], myJ);
+            __syncthreads();
+            const int J = sRed[1];
+            // flat-map offsets over the processed prefix (rank order)
+            int locN[IPT], locT = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int r = tid * IPT + k;
+                locN[k] = (r < J) ? (int)sNch[sProc[r]] : 0;
+                locT += locN[k];
+            }
+            int base = block_excl_scan(locT, T, sWave);
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int r = tid * IPT + k;
+                if (r < J) {
+                    const int i = sProc[r];
+                    sS[i] = base;
+                    sSplit[i] = 1;
+                }
+                base += locN[k];
+            }
+        }
+        __syncthreads();
+
+        // 4. positions of the nodes that stay
+        int locK = 0;
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const int i = tid * IPT + k;
+            locK += (i < n && !sSplit[i]) ? 1 : 0;
+        }
+        int K;
+        int kbase = block_excl_scan(locK, K, sWave);
+        const int newSize = T + K;
+        if (newSize > NC) overflow = true;  // uniform over the block (T, K are block-wide totals)
+        if (overflow) break;
+        if (tid == 0) sRed[2] = 0;
+        __syncthreads();
+
+        // 5. build the new list
+        int locExpand = 0;
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const int i = tid * IPT + k;
+            if (i < n) {
+                if (sSplit[i]) {
+                    const Box b = box[i];
+                    int kk = 0;
+                    const int s = sS[i];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int cc = sCC[4 * i + c];
+                        if (cc > 0) {
+                            const int pos = T - 1 - (s + kk);
+                            nbox[pos] = child_box(b, c);
+                            nncnt[pos] = cc;
+                            sCC[4 * i + c] = pos;
+                            locExpand += cc > 1;
+                            kk++;
+                        }
+                    }
+                } else {
+                    const int pos = T + kbase;
+                    nbox[pos] = box[i];
+                    nncnt[pos] = ncnt[i];
+                    sKeep[i] = pos;
+                    kbase++;
+                }
+            }
+        }
+        if (locExpand) atomicAdd(&sRed[2], locExpand);
+        __syncthreads();
+        const int nToExpand = sRed[2];
+
+        // 6. re-label the points
+        for (int p = tid; p < cL; p += kQtThreads) {
+            const uint32_t cw = C[p];
+            if (PT_WEIGHT(cw)) {
+                const int i = nodeOf[p];
+                nodeOf[p] = (uint16_t)(sSplit[i] ? sCC[4 * i + child_code(box[i], cand_x(cw), cand_y(cw))] : sKeep[i]);
+            }
+        }
+        __syncthreads();
+        n = newSize;
+        cur ^= 1;
+
+        // 7. termination, :358-362 / :424-425
+        if (n >= N || n == prevSize) break;
+        if (!sortedMode && n + 3 * nToExpand > N) sortedMode = true;
+        if (round == kQtMaxRounds - 1 && tid == 0) atomicOr(&cnt[kCntStatus], (uint32_t)kFlagRoundLimit);
+    }
+
+    if (overflow) {
+        if (tid == 0) { cnt[kCntKp] = 0; atomicOr(&cnt[kCntStatus], (uint32_t)kFlagNodeOverflow); }
+        return;
+    }
+
+    // ---- best point per node: max response, first (smallest raster key) wins ties, :515-527 ----
+    int* bestResp = sCC;
+    uint32_t* bestKey = reinterpret_cast<uint32_t*>(sCC + NC);
+    for (int i = tid; i < n; i += kQtThreads) { bestResp[i] = 0; bestKey[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (int p = tid; p < cL; p += kQtThreads) {
+        const uint32_t cw = C[p];
+        if (PT_WEIGHT(cw)) atomicMax(&bestResp[nodeOf[p]], cand_score(cw));
+    }
+    __syncthreads();
+    for (int p = tid; p < cL; p += kQtThreads) {
+        const uint32_t cw = C[p];
+        if (PT_WEIGHT(cw)) {
+            const int i = nodeOf[p];
+            if (cand_score(cw) == bestResp[i]) atomicMin(&bestKey[i], cand_key(cw));
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kQtThreads) out[i] = ((uint32_t)bestResp[i] << 24) | bestKey[i];
+    if (tid == 0) cnt[kCntKp] = (uint32_t)n;
+#undef PT_WEIGHT
+}
+
+int quadtree_node_capacity(int variant) { return variant == 0 ? 512 : 2048; }
+
+void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
+                     const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp)
+{
+    dim3 block(kQtThreads);
+    dim3 grid(frames, nLevels);
+    if (maxNodeCap <= 512)
+        hipLaunchKernelGGL(quadtree_kernel<512>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp);
+    else
+        hipLaunchKernelGGL(quadtree_kernel<2048>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp);
+}
+
+}  // namespace orbfe

@@ -1,0 +1,32 @@
+// launch.h -- host-callable launch wrappers of the gfx950 kernels (one per stage).
+#pragma once
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+// kernels_pyramid.hip
+void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFrameStride, int sw, int sh,
+                   int spitch, uint8_t* dst, size_t dstFrameStride, int dw, int dh, int dpitch,
+                   const uint32_t* xtab, const uint32_t* ytab);
+int blur_tiles_for(int w, int h);
+void launch_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
+                 size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const int* dBlurTileBase);
+
+// kernels_fast.hip
+void fast_tiles_for(int w, int h, int* tx, int* ty);
+void launch_fast(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
+                 size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws, uint32_t* cand,
+                 uint32_t* counters);
+
+// kernels_quadtree.hip
+int quadtree_node_capacity(int variant);
+void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
+                     const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp);
+
+// kernels_desc.hip
+void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const PipelineDesc* dP, const uint8_t* gray0,
+                         size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws, const uint32_t* counters,
+                         const uint32_t* lvlKp, orbfe_keypoint* kpOut, uint8_t* descOut, int* nOut,
+                         int* perLevelOut);
+
+}  // namespace orbfe

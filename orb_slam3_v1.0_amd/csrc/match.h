@@ -1,0 +1,29 @@
+// match.h -- host entry points of the Hamming matchers (kernels_match.hip).
+#pragma once
+#include <string>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+// device + pinned scratch reused across matcher calls (grown on demand, never shrunk)
+struct MatchScratch {
+    void* d = nullptr;      // device arena
+    size_t dBytes = 0;
+    void* hpin = nullptr;   // pinned host arena
+    size_t hBytes = 0;
+};
+
+void match_scratch_free(MatchScratch& m);
+
+int match_projection_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* F, int M,
+                         const orbfe_map_point* mps, const uint8_t* mpDesc, const int* initObs, float th,
+                         int farPoints, float thFar, float nnRatio, int* matchOut, int* nMatches,
+                         std::string& err);
+
+int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const int* kfIdx, const int* fOff,
+                  const int* fIdx, int nKF, const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfHasMP,
+                  int nF, const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation,
+                  int* matchOut, int* nMatches, std::string& err);
+
+}  // namespace orbfe

@@ -1,0 +1,593 @@
+// orbfe_host.cpp -- host orchestration + C ABI (include/orbfe.h) of the MI355X ORB front-end.
+//
+// Mirrors the host side of the reference extractor (src/ORBextractor.cc): constructor tables
+// (:82-149), AllocatePyramid (:587-605), ComputePyramid (:607-623), ComputeKeyPointsOctTree
+// (:433-541) and extractFeatures (:543-585) -- but as ONE ordered chain of asynchronous kernel
+// launches on one HIP stream, with no host synchronisation between stages (the reference syncs
+// >= 8 times per level) and no per-frame allocation.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "launch.h"
+#include "match.h"
+
+using namespace orbfe;
+
+namespace {
+
+constexpr int kEventSets = 128;
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+const char* kStageNames[ORBFE_NUM_STAGES] = {"pyramid_resize", "gauss_blur", "fast_nms",
+                                             "quadtree", "orient_brief", "total"};
+
+}  // namespace
+
+struct orbfe_handle {
+    orbfe_params prm{};
+    int device = 0;
+    int nLevels = 0;
+    double scaleFactorD = 0.0;  // the reference stores scaleFactor as double (ORBextractor.h:108)
+    float sf[kMaxLevels]{}, inv[kMaxLevels]{}, sig2[kMaxLevels]{}, invSig2[kMaxLevels]{};
+    PipelineDesc P{};
+    PipelineDesc* dP = nullptr;
+    int maxBatch = 1;
+    int maxNodeCap = 0;
+    int blurTotalTiles = 0;
+
+    uint8_t* ws = nullptr;          // pyramid + blurred pyramid, all frames
+    size_t wsBytes = 0;
+    uint32_t* dCand = nullptr;      // [level][frame][candCap]
+    uint16_t* dNodeOf = nullptr;
+    size_t candWordsPerBatch = 0;
+    uint32_t* dCounters = nullptr;  // [frame][level][kCntWords]
+    uint32_t* dLvlKp = nullptr;     // [frame][kpCapFrame]
+    uint32_t* dTabs = nullptr;      // resize tables
+    int* dBlurTileBase = nullptr;
+
+    // staging for the host-pointer API
+    uint8_t* dIn = nullptr;
+    int dInPitch = 0;
+    uint8_t* hIn = nullptr;         // pinned
+    orbfe_keypoint* dKp = nullptr;
+    uint8_t* dDesc = nullptr;
+    int* dN = nullptr;
+    int* dPer = nullptr;
+    orbfe_keypoint* hKp = nullptr;  // pinned
+    uint8_t* hDesc = nullptr;
+    int* hN = nullptr;
+    int* hPer = nullptr;
+    uint32_t* hCounters = nullptr;  // pinned copy for status checks
+
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev[kEventSets][ORBFE_NUM_STAGES]{};
+    int evHead = 0, evCount = 0;
+
+    // last call (for the pyramid / candidate getters)
+    const uint8_t* lastGray = nullptr;
+    size_t lastStride = 0;
+    int lastPitch = 0, lastBatch = 0;
+
+    MatchScratch match;
+    std::mutex mu;
+    std::string err;
+};
+
+namespace {
+
+int fail_hip(orbfe_handle* h, hipError_t e, const char* what, int line)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s failed at orbfe_host.cpp:%d: %s", what, line, hipGetErrorString(e));
+    if (h) h->err = buf;
+    return ORBFE_ERR_HIP;
+}
+
+#define HIPCHK(h, call)                                                   \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return fail_hip((h), e_, #call, __LINE__);  \
+    } while (0)
+
+int cv_round_f(float v) { return (int)lrintf(v); }
+
+// resize tables of SPEC DECISION S1: entry = x1 | (Q11 weight << 16)
+void fill_resize_table(std::vector<uint32_t>& t, size_t off, int srcN, int dstN)
+{
+    for (int x = 0; x < dstN; x++) {
+        const int64_t sx = (int64_t)x * srcN;
+        const int x1 = (int)(sx / dstN);
+        const int fx = (int)(sx % dstN);
+        const int wx = (int)(((int64_t)fx * 2048 + dstN / 2) / dstN);
+        t[off + x] = (uint32_t)x1 | ((uint32_t)wx << 16);
+    }
+}
+
+void destroy_impl(orbfe_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& set : h->ev)
+        for (auto& e : set)
+            if (e) (void)hipEventDestroy(e);
+    match_scratch_free(h->match);
+    void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTabs,
+                     h->dBlurTileBase, h->dIn, h->dKp, h->dDesc, h->dN, h->dPer};
+    for (void* p : dptrs)
+        if (p) (void)hipFree(p);
+    void* hptrs[] = {h->hIn, h->hKp, h->hDesc, h->hN, h->hPer, h->hCounters};
+    for (void* p : hptrs)
+        if (p) (void)hipHostFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* orbfe_version(void) { return "orbfe 0.1 (gfx950, HIP)"; }
+
+const char* orbfe_status_string(int s)
+{
+    switch (s) {
+    case ORBFE_OK: return "ok";
+    case ORBFE_ERR_INVALID_ARG: return "invalid argument";
+    case ORBFE_ERR_UNSUPPORTED: return "unsupported configuration";
+    case ORBFE_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case ORBFE_ERR_HIP: return "HIP runtime error";
+    case ORBFE_ERR_OUT_OF_MEMORY: return "out of memory";
+    case ORBFE_ERR_INTERNAL: return "internal device-side guard tripped";
+    default: return "unknown status";
+    }
+}
+
+const char* orbfe_last_error(const orbfe_handle* h) { return h ? h->err.c_str() : ""; }
+const char* orbfe_stage_name(int s) { return (s >= 0 && s < ORBFE_NUM_STAGES) ? kStageNames[s] : ""; }
+
+int orbfe_create(const orbfe_params* p, orbfe_handle** out)
+{
+    if (!p || !out) return ORBFE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (p->n_levels < 1 || p->n_levels > kMaxLevels || p->image_width < 16 || p->image_height < 16 ||
+        p->n_features < 0 || p->n_fast_features < 1 || p->max_batch < 1 || !(p->scale_factor > 1.0f))
+        return ORBFE_ERR_INVALID_ARG;
+    // one fused FAST pass serves both thresholds only when iniThFAST >= minThFAST >= 1
+    if (p->min_th_fast < 1 || p->ini_th_fast < p->min_th_fast || p->ini_th_fast > 254)
+        return ORBFE_ERR_UNSUPPORTED;
+    if (p->image_width > (int)kCoordMask || p->image_height > (int)kCoordMask) return ORBFE_ERR_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device_id < 0 || p->device_id >= ndev)
+        return ORBFE_ERR_NO_DEVICE;
+    if (hipSetDevice(p->device_id) != hipSuccess) return ORBFE_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device_id) != hipSuccess) return ORBFE_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ORBFE_ERR_NO_DEVICE;  // code object is gfx950 only
+
+    orbfe_handle* h = new (std::nothrow) orbfe_handle();
+    if (!h) return ORBFE_ERR_OUT_OF_MEMORY;
+    h->prm = *p;
+    h->device = p->device_id;
+    h->nLevels = p->n_levels;
+    h->maxBatch = p->max_batch;
+    const int nL = p->n_levels;
+
+    // ---- scale tables, src/ORBextractor.cc:92-108 ----
+    h->scaleFactorD = p->scale_factor;
+    h->sf[0] = 1.0f;
+    h->sig2[0] = 1.0f;
+    for (int i = 1; i < nL; i++) {
+        h->sf[i] = (float)(h->sf[i - 1] * h->scaleFactorD);
+        h->sig2[i] = h->sf[i] * h->sf[i];
+    }
+    for (int i = 0; i < nL; i++) {
+        h->inv[i] = 1.0f / h->sf[i];
+        h->invSig2[i] = 1.0f / h->sig2[i];
+    }
+    // ---- features per level, :112-124 ----
+    int fpl[kMaxLevels];
+    {
+        const float factor = (float)(1.0f / h->scaleFactorD);
+        float nDesired = (float)p->n_features * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nL));
+        int sum = 0;
+        for (int l = 0; l < nL - 1; l++) {
+            fpl[l] = cv_round_f(nDesired);
+            sum += fpl[l];
+            nDesired *= factor;
+        }
+        fpl[nL - 1] = std::max(p->n_features - sum, 0);
+    }
+
+    // ---- level geometry (AllocatePyramid :587-605) + workspace layout ----
+    PipelineDesc& P = h->P;
+    memset(&P, 0, sizeof P);
+    P.nLevels = nL;
+    P.nFast = p->n_fast_features;
+    P.iniTh = p->ini_th_fast;
+    P.minTh = p->min_th_fast;
+    size_t wsOff = 0, candOff = 0, tabOff = 0;
+    int tileBase = 0, kpBase = 0, blurTiles = 0;
+    std::vector<int> blurTileBase(nL + 1, 0);
+    const size_t B = (size_t)p->max_batch;
+    int status = ORBFE_OK;
+    for (int l = 0; l < nL; l++) {
+        LevelDesc& L = P.lv[l];
+        if (l == 0) {
+            L.w = p->image_width;
+            L.h = p->image_height;
+        } else {
+            L.w = cv_round_f(h->inv[l] * (float)p->image_width);
+            L.h = cv_round_f(h->inv[l] * (float)p->image_height);
+        }
+        if (L.w < 16 || L.h < 16) { status = ORBFE_ERR_UNSUPPORTED; break; }
+        L.pitch = (int)align_up((size_t)L.w, kPitchAlign);
+        L.nFeatures = fpl[l];
+        L.nIni = (int)roundf((float)L.w / (float)L.h);  // :231
+        if (L.nIni < 1) { status = ORBFE_ERR_UNSUPPORTED; break; }  // the reference divides by zero here
+        L.hX = (float)L.w / (float)L.nIni;                // :233
+        L.nodeCap = std::max(L.nFeatures + 3, 4 * L.nIni);
+        L.candCap = ((L.w + 1) / 2) * ((L.h + 1) / 2);
+        fast_tiles_for(L.w, L.h, &L.tilesX, &L.tilesY);
+        L.tileBase = tileBase;
+        tileBase += L.tilesX * L.tilesY;
+        L.kpBase = kpBase;
+        kpBase += L.nodeCap;
+        L.invScale = h->inv[l];
+        L.scaledPatch = (int)(kPatch * h->inv[l]);         // :511
+        const size_t frameBytes = align_up((size_t)L.pitch * L.h, 256);
+        L.imgFrameStride = frameBytes;
+        L.blurFrameStride = frameBytes;
+        if (l > 0) {
+            L.imgOff = wsOff;
+            wsOff += frameBytes * B;
+        }
+        L.blurOff = wsOff;
+        wsOff += frameBytes * B;
+        L.candOff = candOff;
+        candOff += (size_t)L.candCap * B;
+        L.xtabOff = tabOff;
+        tabOff += (size_t)L.w;
+        L.ytabOff = tabOff;
+        tabOff += (size_t)L.h;
+        blurTileBase[l] = blurTiles;
+        blurTiles += blur_tiles_for(L.w, L.h);
+        h->maxNodeCap = std::max(h->maxNodeCap, L.nodeCap);
+    }
+    blurTileBase[nL] = blurTiles;
+    if (status == ORBFE_OK && h->maxNodeCap > quadtree_node_capacity(1)) status = ORBFE_ERR_UNSUPPORTED;
+    if (status != ORBFE_OK) {
+        delete h;
+        return status;
+    }
+    P.kpCapFrame = kpBase;
+    P.totalTiles = tileBase;
+    h->blurTotalTiles = blurTiles;
+    h->wsBytes = wsOff;
+    h->candWordsPerBatch = candOff;
+
+    std::vector<uint32_t> tabs(tabOff ? tabOff : 1, 0);
+    for (int l = 1; l < nL; l++) {
+        fill_resize_table(tabs, P.lv[l].xtabOff, P.lv[l - 1].w, P.lv[l].w);
+        fill_resize_table(tabs, P.lv[l].ytabOff, P.lv[l - 1].h, P.lv[l].h);
+    }
+
+#define CREATE_CHK(call)                                                  \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) {                                           \
+            int rc_ = e_ == hipErrorOutOfMemory ? ORBFE_ERR_OUT_OF_MEMORY : ORBFE_ERR_HIP; \
+            destroy_impl(h);                                              \
+            return rc_;                                                   \
+        }                                                                 \
+    } while (0)
+
+    CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipMalloc(&h->dP, sizeof(PipelineDesc)));
+    CREATE_CHK(hipMalloc(&h->ws, h->wsBytes));
+    CREATE_CHK(hipMalloc(&h->dCand, candOff * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(&h->dNodeOf, candOff * sizeof(uint16_t)));
+    CREATE_CHK(hipMalloc(&h->dCounters, B * nL * kCntWords * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(&h->dLvlKp, B * (size_t)P.kpCapFrame * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(&h->dTabs, tabs.size() * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(&h->dBlurTileBase, (nL + 1) * sizeof(int)));
+    CREATE_CHK(hipMemcpy(h->dP, &P, sizeof P, hipMemcpyHostToDevice));
+    CREATE_CHK(hipMemcpy(h->dTabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CREATE_CHK(hipMemcpy(h->dBlurTileBase, blurTileBase.data(), (nL + 1) * sizeof(int), hipMemcpyHostToDevice));
+
+    // staging for the host-pointer entry points
+    h->dInPitch = (int)align_up((size_t)p->image_width, kPitchAlign);
+    const size_t inFrame = (size_t)h->dInPitch * p->image_height;
+    const size_t cap = (size_t)P.kpCapFrame;
+    CREATE_CHK(hipMalloc(&h->dIn, inFrame * B));
+    CREATE_CHK(hipHostMalloc(&h->hIn, inFrame * B));
+    CREATE_CHK(hipMalloc(&h->dKp, B * cap * sizeof(orbfe_keypoint)));
+    CREATE_CHK(hipMalloc(&h->dDesc, B * cap * ORBFE_DESC_BYTES));
+    CREATE_CHK(hipMalloc(&h->dN, B * sizeof(int)));
+    CREATE_CHK(hipMalloc(&h->dPer, B * nL * sizeof(int)));
+    CREATE_CHK(hipHostMalloc(&h->hKp, B * cap * sizeof(orbfe_keypoint)));
+    CREATE_CHK(hipHostMalloc(&h->hDesc, B * cap * ORBFE_DESC_BYTES));
+    CREATE_CHK(hipHostMalloc(&h->hN, B * sizeof(int)));
+    CREATE_CHK(hipHostMalloc(&h->hPer, B * nL * sizeof(int)));
+    CREATE_CHK(hipHostMalloc(&h->hCounters, B * nL * kCntWords * sizeof(uint32_t)));
+    for (auto& set : h->ev)
+        for (auto& e : set) CREATE_CHK(hipEventCreate(&e));
+#undef CREATE_CHK
+    *out = h;
+    return ORBFE_OK;
+}
+
+void orbfe_destroy(orbfe_handle* h) { destroy_impl(h); }
+
+int orbfe_get_levels(const orbfe_handle* h) { return h ? h->nLevels : 0; }
+float orbfe_get_scale_factor(const orbfe_handle* h) { return h ? (float)h->scaleFactorD : 0.f; }
+
+int orbfe_get_scale_tables(const orbfe_handle* h, float* sf, float* inv, float* s2, float* is2)
+{
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < h->nLevels; i++) {
+        if (sf) sf[i] = h->sf[i];
+        if (inv) inv[i] = h->inv[i];
+        if (s2) s2[i] = h->sig2[i];
+        if (is2) is2[i] = h->invSig2[i];
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_get_level_info(const orbfe_handle* h, int* fpl, int* lw, int* lh)
+{
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < h->nLevels; i++) {
+        if (fpl) fpl[i] = h->P.lv[i].nFeatures;
+        if (lw) lw[i] = h->P.lv[i].w;
+        if (lh) lh[i] = h->P.lv[i].h;
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_max_keypoints(const orbfe_handle* h) { return h ? h->P.kpCapFrame : 0; }
+
+int orbfe_set_stage_timing(orbfe_handle* h, int enabled)
+{
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    h->timing = enabled != 0;
+    h->evHead = h->evCount = 0;
+    return ORBFE_OK;
+}
+
+int orbfe_get_stage_ms(orbfe_handle* h, float ms[ORBFE_NUM_STAGES], int* n_calls)
+{
+    if (!h || !ms || !n_calls) return ORBFE_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int s = 0; s < ORBFE_NUM_STAGES; s++) ms[s] = 0.f;
+    const int n = h->evCount < kEventSets ? h->evCount : kEventSets;
+    for (int i = 0; i < n; i++) {
+        hipEvent_t* e = h->ev[i];
+        HIPCHK(h, hipEventSynchronize(e[ORBFE_NUM_STAGES - 1]));
+        for (int s = 0; s + 1 < ORBFE_NUM_STAGES; s++) {
+            float t = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&t, e[s], e[s + 1]));
+            ms[s] += t;
+        }
+        float t = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&t, e[0], e[ORBFE_NUM_STAGES - 1]));
+        ms[ORBFE_NUM_STAGES - 1] += t;
+    }
+    *n_calls = n;
+    return ORBFE_OK;
+}
+
+int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t frame_stride, int pitch,
+                               int batch, orbfe_keypoint* d_kp, uint8_t* d_desc, int* d_n, int* d_per,
+                               void* stream_)
+{
+    if (!h || !d_gray || !d_kp || !d_desc || !d_n) return ORBFE_ERR_INVALID_ARG;
+    if (batch < 1 || batch > h->maxBatch || pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
+    if (batch > 1 && frame_stride < (size_t)pitch * (h->prm.image_height - 1) + h->prm.image_width)
+        return ORBFE_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
+    const PipelineDesc& P = h->P;
+    const int nL = P.nLevels;
+    hipEvent_t* ev = nullptr;
+    if (h->timing) {
+        ev = h->ev[h->evHead];
+        h->evHead = (h->evHead + 1) % kEventSets;
+        h->evCount++;
+    }
+    const int aligned4 = ((reinterpret_cast<uintptr_t>(d_gray) | (uintptr_t)pitch | (uintptr_t)frame_stride) & 3u) == 0;
+
+    HIPCHK(h, hipMemsetAsync(h->dCounters, 0, (size_t)batch * nL * kCntWords * sizeof(uint32_t), s));
+    if (ev) HIPCHK(h, hipEventRecord(ev[0], s));
+    // ComputePyramid (:607-623): level l from the UNBLURRED level l-1
+    for (int l = 1; l < nL; l++) {
+        const LevelDesc& S = P.lv[l - 1];
+        const LevelDesc& D = P.lv[l];
+        const uint8_t* src = l == 1 ? d_gray : h->ws + S.imgOff;
+        const size_t sstride = l == 1 ? frame_stride : S.imgFrameStride;
+        const int spitch = l == 1 ? pitch : S.pitch;
+        launch_resize(s, batch, src, sstride, S.w, S.h, spitch, h->ws + D.imgOff, D.imgFrameStride, D.w, D.h,
+                      D.pitch, h->dTabs + D.xtabOff, h->dTabs + D.ytabOff);
+    }
+    if (ev) HIPCHK(h, hipEventRecord(ev[1], s));
+    launch_blur(s, batch, h->blurTotalTiles, h->dP, d_gray, frame_stride, pitch, h->ws, h->dBlurTileBase);
+    if (ev) HIPCHK(h, hipEventRecord(ev[2], s));
+    launch_fast(s, batch, P.totalTiles, h->dP, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters);
+    if (ev) HIPCHK(h, hipEventRecord(ev[3], s));
+    launch_quadtree(s, batch, nL, h->maxNodeCap, h->dP, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp);
+    if (ev) HIPCHK(h, hipEventRecord(ev[4], s));
+    launch_orient_brief(s, batch, P.kpCapFrame, h->dP, d_gray, frame_stride, pitch, h->ws, h->dCounters, h->dLvlKp,
+                        d_kp, d_desc, d_n, d_per);
+    if (ev) HIPCHK(h, hipEventRecord(ev[5], s));
+    HIPCHK(h, hipGetLastError());
+    h->lastGray = d_gray;
+    h->lastStride = frame_stride;
+    h->lastPitch = pitch;
+    h->lastBatch = batch;
+    return ORBFE_OK;
+}
+
+static int check_device_flags(orbfe_handle* h, int batch)
+{
+    // caller has synchronised the stream; hCounters holds the counters of the call
+    const int nL = h->nLevels;
+    for (int i = 0; i < batch * nL; i++)
+        if (h->hCounters[(size_t)i * kCntWords + kCntStatus]) {
+            char buf[128];
+            snprintf(buf, sizeof buf, "device guard flags 0x%x at frame %d level %d",
+                     h->hCounters[(size_t)i * kCntWords + kCntStatus], i / nL, i % nL);
+            h->err = buf;
+            return ORBFE_ERR_INTERNAL;
+        }
+    return ORBFE_OK;
+}
+
+int orbfe_extract_batch(orbfe_handle* h, const uint8_t* const* grays, int pitch, int batch, orbfe_keypoint* kp_out,
+                        uint8_t* desc_out, int* n_out, int* per_level)
+{
+    if (!h || !grays || !kp_out || !desc_out || !n_out) return ORBFE_ERR_INVALID_ARG;
+    if (batch < 1 || batch > h->maxBatch || pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;
+    const size_t inFrame = (size_t)h->dInPitch * H;
+    for (int b = 0; b < batch; b++) {
+        if (!grays[b]) return ORBFE_ERR_INVALID_ARG;
+        for (int y = 0; y < H; y++)
+            memcpy(h->hIn + b * inFrame + (size_t)y * h->dInPitch, grays[b] + (size_t)y * pitch, (size_t)W);
+    }
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->dIn, h->hIn, inFrame * batch, hipMemcpyHostToDevice, s));
+    int rc = orbfe_extract_batch_device(h, h->dIn, inFrame, h->dInPitch, batch, h->dKp, h->dDesc, h->dN, h->dPer, s);
+    if (rc != ORBFE_OK) return rc;
+    const size_t cap = (size_t)h->P.kpCapFrame;
+    HIPCHK(h, hipMemcpyAsync(h->hN, h->dN, batch * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->hPer, h->dPer, (size_t)batch * nL * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->hKp, h->dKp, batch * cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->hDesc, h->dDesc, batch * cap * ORBFE_DESC_BYTES, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->hCounters, h->dCounters, (size_t)batch * nL * kCntWords * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    rc = check_device_flags(h, batch);
+    if (rc != ORBFE_OK) return rc;
+    for (int b = 0; b < batch; b++) {
+        const int n = h->hN[b];
+        n_out[b] = n;
+        memcpy(kp_out + b * cap, h->hKp + b * cap, (size_t)n * sizeof(orbfe_keypoint));
+        memcpy(desc_out + b * cap * ORBFE_DESC_BYTES, h->hDesc + b * cap * ORBFE_DESC_BYTES, (size_t)n * ORBFE_DESC_BYTES);
+        if (per_level) memcpy(per_level + (size_t)b * nL, h->hPer + (size_t)b * nL, nL * sizeof(int));
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_extract(orbfe_handle* h, const uint8_t* gray, int pitch, orbfe_keypoint* kp_out, uint8_t* desc_out,
+                  int* n_out, int* per_level)
+{
+    const uint8_t* one[1] = {gray};
+    return orbfe_extract_batch(h, one, pitch, 1, kp_out, desc_out, n_out, per_level);
+}
+
+int orbfe_get_pyramid_level(orbfe_handle* h, int frame, int level, int blurred, uint8_t* out, int out_pitch)
+{
+    if (!h || !out || level < 0 || level >= h->nLevels || frame < 0 || frame >= h->lastBatch) return ORBFE_ERR_INVALID_ARG;
+    const LevelDesc& L = h->P.lv[level];
+    if (out_pitch < L.w) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint8_t* src;
+    size_t spitch;
+    if (blurred) {
+        src = h->ws + L.blurOff + (size_t)frame * L.blurFrameStride;
+        spitch = L.pitch;
+    } else if (level == 0) {
+        src = h->lastGray + (size_t)frame * h->lastStride;
+        spitch = h->lastPitch;
+    } else {
+        src = h->ws + L.imgOff + (size_t)frame * L.imgFrameStride;
+        spitch = L.pitch;
+    }
+    HIPCHK(h, hipMemcpy2D(out, out_pitch, src, spitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_debug_get_candidates(orbfe_handle* h, int frame, int level, uint32_t* packed, int cap, int* n_out,
+                               int counters[4])
+{
+    if (!h || !n_out || level < 0 || level >= h->nLevels || frame < 0 || frame >= h->lastBatch) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint32_t c[kCntWords];
+    HIPCHK(h, hipMemcpy(c, h->dCounters + ((size_t)frame * h->nLevels + level) * kCntWords, sizeof c, hipMemcpyDeviceToHost));
+    const LevelDesc& L = h->P.lv[level];
+    int n = (int)std::min<uint32_t>(c[kCntCand], (uint32_t)L.candCap);
+    if (counters) {
+        counters[0] = (int)c[kCntCand];
+        counters[1] = (int)c[kCntHigh];
+        counters[2] = (int)c[kCntPreLow];
+        counters[3] = (int)c[kCntPreHigh];
+    }
+    const int m = std::min(n, cap);
+    if (packed && m > 0)
+        HIPCHK(h, hipMemcpy(packed, h->dCand + L.candOff + (size_t)frame * L.candCap, (size_t)m * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost));
+    *n_out = m;
+    return ORBFE_OK;
+}
+
+int orbfe_hamming(const uint8_t* a, const uint8_t* b)
+{
+    // ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1375-1391): popcount of the 256-bit XOR
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+int orbfe_match_projection(orbfe_handle* h, const orbfe_frame_view* F, int M, const orbfe_map_point* mps,
+                           const uint8_t* mp_desc, const int* init_obs, float th, int far_points, float th_far,
+                           float nn_ratio, int* match_out, int* n_matches)
+{
+    if (!h || !F || !match_out || !n_matches || M < 0 || F->n < 0) return ORBFE_ERR_INVALID_ARG;
+    if ((M > 0 && (!mps || !mp_desc)) || (F->n > 0 && (!F->kp || !F->desc)) || !F->scale_factors) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    int rc = match_projection_run(h->match, h->stream, F, M, mps, mp_desc, init_obs, th, far_points, th_far, nn_ratio,
+                                  match_out, n_matches, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+int orbfe_match_bow(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx, const int* f_off, const int* f_idx,
+                    int n_kf, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_has_mp, int n_f,
+                    const uint8_t* f_desc, const float* f_angle, float nn_ratio, int check_orientation, int* match_out,
+                    int* n_matches)
+{
+    if (!h || !match_out || !n_matches || G < 0 || n_kf < 0 || n_f < 0) return ORBFE_ERR_INVALID_ARG;
+    if (G > 0 && (!kf_off || !kf_idx || !f_off || !f_idx || !kf_desc || !f_desc || !kf_has_mp)) return ORBFE_ERR_INVALID_ARG;
+    if (check_orientation && G > 0 && (!kf_angle || !f_angle)) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    int rc = match_bow_run(h->match, h->stream, G, kf_off, kf_idx, f_off, f_idx, n_kf, kf_desc, kf_angle, kf_has_mp, n_f,
+                           f_desc, f_angle, nn_ratio, check_orientation, match_out, n_matches, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+"""orbfe -- ctypes binding of liborbfe.so (include/orbfe.h) with the reference's class names.
+
+`ORBextractor` / `ORBmatcher` mirror include/ORBextractor.h:52-130 and include/ORBmatcher.h:36-84 of
+geoeo/ORB_SLAM3_V1.0 (same constructor arguments, same method names, same results) so the parity
+tests read like calls into the reference.  This module is plumbing: every result comes from the
+HIP kernels behind the C ABI.  There is NO CPU fallback -- if liborbfe.so is missing or no gfx950
+device is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
+LIB_PATH = os.path.join(CSRC, "liborbfe.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<i4"), ("size", "<f4"),
+                     ("octave", "<i4"), ("angle", "<f4")])
+MP_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("view_cos", "<f4"), ("track_depth", "<f4"),
+                     ("level", "<i4"), ("in_view", "<i4"), ("bad", "<i4"), ("observations", "<i4")])
+NUM_STAGES = 6
+
+STATUS = {0: "ORBFE_OK", 1: "ORBFE_ERR_INVALID_ARG", 2: "ORBFE_ERR_UNSUPPORTED", 3: "ORBFE_ERR_NO_DEVICE",
+          4: "ORBFE_ERR_HIP", 5: "ORBFE_ERR_OUT_OF_MEMORY", 6: "ORBFE_ERR_INTERNAL"}
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__("%s: %s (%d) %s" % (where, STATUS.get(code, "?"), code, detail))
+
+
+class Params(C.Structure):
+    _fields_ = [("n_features", C.c_int), ("n_fast_features", C.c_int), ("scale_factor", C.c_float),
+                ("n_levels", C.c_int), ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int),
+                ("image_width", C.c_int), ("image_height", C.c_int), ("device_id", C.c_int),
+                ("max_batch", C.c_int)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int), ("kp", C.c_void_p), ("desc", C.c_void_p), ("grid_cols", C.c_int),
+                ("grid_rows", C.c_int), ("min_x", C.c_float), ("min_y", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("n_levels", C.c_int),
+                ("scale_factors", C.c_void_p)]
+
+
+# every symbol include/orbfe.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "orbfe_create", "orbfe_destroy", "orbfe_get_levels", "orbfe_get_scale_factor", "orbfe_get_scale_tables",
+    "orbfe_get_level_info", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+    "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
+    "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
+    "orbfe_match_projection", "orbfe_match_bow", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+]
+
+_lib = None
+
+
+def lib():
+    """Load liborbfe.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("liborbfe.so not found at %s -- run __graft_entry__.build() (hipcc, gfx950); "
+                           "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orbfe_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.orbfe_destroy.argtypes = [vp]
+    L.orbfe_destroy.restype = None
+    L.orbfe_get_levels.argtypes = [vp]
+    L.orbfe_get_scale_factor.argtypes = [vp]
+    L.orbfe_get_scale_factor.restype = cf
+    L.orbfe_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orbfe_get_level_info.argtypes = [vp, vp, vp, vp]
+    L.orbfe_max_keypoints.argtypes = [vp]
+    L.orbfe_extract.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    L.orbfe_extract_batch.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    L.orbfe_extract_batch_device.argtypes = [vp, vp, sz, ci, ci, vp, vp, vp, vp, vp]
+    L.orbfe_get_pyramid_level.argtypes = [vp, ci, ci, ci, vp, ci]
+    L.orbfe_debug_get_candidates.argtypes = [vp, ci, ci, vp, ci, vp, vp]
+    L.orbfe_set_stage_timing.argtypes = [vp, ci]
+    L.orbfe_get_stage_ms.argtypes = [vp, vp, vp]
+    L.orbfe_stage_name.argtypes = [ci]
+    L.orbfe_stage_name.restype = C.c_char_p
+    L.orbfe_hamming.argtypes = [vp, vp]
+    L.orbfe_match_projection.argtypes = [vp, C.POINTER(FrameView), ci, vp, vp, vp, cf, ci, cf, cf, vp, vp]
+    L.orbfe_match_bow.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp, vp]
+    L.orbfe_status_string.argtypes = [ci]
+    L.orbfe_status_string.restype = C.c_char_p
+    L.orbfe_last_error.argtypes = [vp]
+    L.orbfe_last_error.restype = C.c_char_p
+    L.orbfe_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class ORBextractor:
+    """ORB_SLAM3::ORBextractor (include/ORBextractor.h:52-130) on one MI355X."""
+
+    def __init__(self, nFeatures, nFastFeatures, scaleFactor, nlevels, iniThFAST, minThFAST, imageWidth,
+                 imageHeight, device=0, max_batch=1):
+        self.L = lib()
+        self.h = C.c_void_p()
+        prm = Params(nFeatures, nFastFeatures, scaleFactor, nlevels, iniThFAST, minThFAST, imageWidth,
+                     imageHeight, device, max_batch)
+        rc = self.L.orbfe_create(C.byref(prm), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise OrbfeError(rc, "orbfe_create")
+        self.nlevels, self.W, self.H, self.max_batch = nlevels, imageWidth, imageHeight, max_batch
+        self.cap = self.L.orbfe_max_keypoints(self.h)
+        n = nlevels
+        self.mvScaleFactor = np.zeros(n, np.float32)
+        self.mvInvScaleFactor = np.zeros(n, np.float32)
+        self.mvLevelSigma2 = np.zeros(n, np.float32)
+        self.mvInvLevelSigma2 = np.zeros(n, np.float32)
+        self._chk(self.L.orbfe_get_scale_tables(self.h, _p(self.mvScaleFactor), _p(self.mvInvScaleFactor),
+                                                _p(self.mvLevelSigma2), _p(self.mvInvLevelSigma2)), "scale_tables")
+        self.mnFeaturesPerLevel = np.zeros(n, np.int32)
+        self.levelW = np.zeros(n, np.int32)
+        self.levelH = np.zeros(n, np.int32)
+        self._chk(self.L.orbfe_get_level_info(self.h, _p(self.mnFeaturesPerLevel), _p(self.levelW), _p(self.levelH)),
+                  "level_info")
+
+    def _chk(self, rc, where):
+        if rc != 0:
+            raise OrbfeError(rc, where, self.L.orbfe_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # getters, include/ORBextractor.h:64-92
+    def GetLevels(self):
+        return self.L.orbfe_get_levels(self.h)
+
+    def GetScaleFactor(self):
+        return self.L.orbfe_get_scale_factor(self.h)
+
+    def GetScaleFactors(self):
+        return self.mvScaleFactor.copy()
+
+    def GetInverseScaleFactors(self):
+        return self.mvInvScaleFactor.copy()
+
+    def GetScaleSigmaSquares(self):
+        return self.mvLevelSigma2.copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self.mvInvLevelSigma2.copy()
+
+    def extractFeatures(self, im):
+        """extractFeatures (include/ORBextractor.h:62): returns (keypoints, descriptors) or None."""
+        im = np.asarray(im)
+        assert im.dtype == np.uint8 and im.shape == (self.H, self.W) and im.strides[1] == 1
+        kp = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int()
+        self.last_per_level = np.zeros(self.nlevels, np.int32)
+        self._chk(self.L.orbfe_extract(self.h, _p(im), im.strides[0], _p(kp), _p(desc), C.byref(n),
+                                       _p(self.last_per_level)), "orbfe_extract")
+        if n.value == 0:
+            return None
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, ims):
+        """Host-pointer batched mode: list/array of frames -> list of (kp, desc, per_level)."""
+        ims = [np.ascontiguousarray(im, np.uint8) for im in ims]
+        B = len(ims)
+        assert 1 <= B <= self.max_batch
+        ptrs = (C.c_void_p * B)(*[im.ctypes.data for im in ims])
+        kp = np.zeros((B, self.cap), KP_DTYPE)
+        desc = np.zeros((B, self.cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        per = np.zeros((B, self.nlevels), np.int32)
+        self._chk(self.L.orbfe_extract_batch(self.h, ptrs, self.W, B, _p(kp), _p(desc), _p(n), _p(per)),
+                  "orbfe_extract_batch")
+        return [(kp[b, :n[b]].copy(), desc[b, :n[b]].copy(), per[b].copy()) for b in range(B)]
+
+    def extract_batch_device(self, d_gray_ptr, frame_stride, pitch, batch, d_kp_ptr, d_desc_ptr, d_n_ptr,
+                             d_per_ptr=None, stream=None):
+        """Everything resident in HBM (raw device pointers as ints); asynchronous on `stream`."""
+        self._chk(self.L.orbfe_extract_batch_device(self.h, d_gray_ptr, frame_stride, pitch, batch, d_kp_ptr,
+                                                    d_desc_ptr, d_n_ptr, d_per_ptr, stream),
+                  "orbfe_extract_batch_device")
+
+    # mvImagePyramid / mvBlurredImagePyramid (include/ORBextractor.h:94-95)
+    def pyramid_level(self, level, blurred=False, frame=0):
+        w, h = int(self.levelW[level]), int(self.levelH[level])
+        out = np.zeros((h, w), np.uint8)
+        self._chk(self.L.orbfe_get_pyramid_level(self.h, frame, level, int(blurred), _p(out), w), "pyramid_level")
+        return out
+
+    def debug_candidates(self, level, frame=0):
+        cap = ((int(self.levelW[level]) + 1) // 2) * ((int(self.levelH[level]) + 1) // 2)
+        packed = np.zeros(cap, np.uint32)
+        n = C.c_int()
+        cnt = np.zeros(4, np.int32)
+        self._chk(self.L.orbfe_debug_get_candidates(self.h, frame, level, _p(packed), cap, C.byref(n), _p(cnt)),
+                  "debug_candidates")
+        return packed[:n.value].copy(), cnt
+
+    def set_stage_timing(self, on):
+        self._chk(self.L.orbfe_set_stage_timing(self.h, int(on)), "set_stage_timing")
+
+    def stage_ms(self):
+        ms = np.zeros(NUM_STAGES, np.float32)
+        n = C.c_int()
+        self._chk(self.L.orbfe_get_stage_ms(self.h, _p(ms), C.byref(n)), "get_stage_ms")
+        names = [self.L.orbfe_stage_name(i).decode() for i in range(NUM_STAGES)]
+        return dict(zip(names, ms.tolist())), n.value
+
+
+def make_frame_view(kp, desc, gridCols, gridRows, minX, minY, maxX, maxY, scaleFactors):
+    """Frame grid statics exactly as src/Frame.cc:101-105 derives them."""
+    kp = np.ascontiguousarray(kp, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    sf = np.ascontiguousarray(scaleFactors, np.float32)
+    invw = np.float32(gridCols) / np.float32(np.float32(maxX) - np.float32(minX))
+    invh = np.float32(gridRows) / np.float32(np.float32(maxY) - np.float32(minY))
+    fv = FrameView(len(kp), kp.ctypes.data, desc.ctypes.data, gridCols, gridRows, minX, minY, float(invw),
+                   float(invh), len(sf), sf.ctypes.data)
+    fv._keep = (kp, desc, sf)
+    return fv
+
+
+class ORBmatcher:
+    """ORB_SLAM3::ORBmatcher (include/ORBmatcher.h:36-84); statics bound to one extractor handle."""
+    TH_LOW = 30
+    TH_HIGH = 100
+    HISTO_LENGTH = 30
+
+    def __init__(self, extractor):
+        self.e = extractor
+        self.L = extractor.L
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return lib().orbfe_hamming(_p(a), _p(b))
+
+    def SearchByProjection(self, fv, mps, mpDesc, th, bFarPoints, thFarPoints, nnRatio, initObs=None):
+        mps = np.ascontiguousarray(mps, MP_DTYPE)
+        mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+        io = None if initObs is None else np.ascontiguousarray(initObs, np.int32)
+        out = np.full(max(1, fv.n), -1, np.int32)
+        n = C.c_int()
+        self.e._chk(self.L.orbfe_match_projection(self.e.h, C.byref(fv), len(mps), _p(mps), _p(mpDesc), _p(io), th,
+                                                  int(bFarPoints), thFarPoints, nnRatio, _p(out), C.byref(n)),
+                    "orbfe_match_projection")
+        return n.value, out[:fv.n].copy()
+
+    def SearchByBoW(self, kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAngle, nnRatio,
+                    checkOrientation=True):
+        a32 = lambda v: np.ascontiguousarray(v, np.int32)
+        kfOff, kfIdx, fOff, fIdx = a32(kfOff), a32(kfIdx), a32(fOff), a32(fIdx)
+        kfDesc = np.ascontiguousarray(kfDesc, np.uint8)
+        fDesc = np.ascontiguousarray(fDesc, np.uint8)
+        kfAngle = np.ascontiguousarray(kfAngle, np.float32)
+        fAngle = np.ascontiguousarray(fAngle, np.float32)
+        kfHasMP = np.ascontiguousarray(kfHasMP, np.uint8)
+        out = np.full(max(1, len(fDesc)), -1, np.int32)
+        n = C.c_int()
+        self.e._chk(self.L.orbfe_match_bow(self.e.h, len(kfOff) - 1, _p(kfOff), _p(kfIdx), _p(fOff), _p(fIdx),
+                                           len(kfDesc), _p(kfDesc), _p(kfAngle), _p(kfHasMP), len(fDesc), _p(fDesc),
+                                           _p(fAngle), nnRatio, int(checkOrientation), _p(out), C.byref(n)),
+                    "orbfe_match_bow")
+        return n.value, out[:len(fDesc)].copy()

@@ -1,0 +1,238 @@
+"""ctypes loader for the CPU oracle (oracle/liborb_oracle.so).  Tests / bench cpu_baseline only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<i4"), ("size", "<f4"),
+                     ("octave", "<i4"), ("angle", "<f4")])
+assert KP_DTYPE.itemsize == 24
+
+MP_DTYPE = np.dtype([("projX", "<f4"), ("projY", "<f4"), ("viewCos", "<f4"), ("trackDepth", "<f4"),
+                     ("level", "<i4"), ("inView", "<i4"), ("bad", "<i4"), ("observations", "<i4")])
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int), ("kp", C.c_void_p), ("desc", C.c_void_p), ("gridCols", C.c_int),
+                ("gridRows", C.c_int), ("minX", C.c_float), ("minY", C.c_float),
+                ("gridInvW", C.c_float), ("gridInvH", C.c_float), ("nLevels", C.c_int),
+                ("scaleFactors", C.c_void_p)]
+
+
+def build(asan=False):
+    target = "liborb_oracle_asan.so" if asan else "liborb_oracle.so"
+    subprocess.check_call(["make", "-s", "-C", ODIR, target])
+    return os.path.join(ODIR, target)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ODIR, "liborb_oracle.so")
+        srcs = ("orb_oracle.c", "match_oracle.c", "orb_oracle.h")
+        if not os.path.exists(path) or any(
+                os.path.getmtime(os.path.join(ODIR, f)) > os.path.getmtime(path) for f in srcs):
+            build()
+        L = C.CDLL(path)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.orc_create.restype = vp
+        L.orc_create.argtypes = [ci, ci, cf, ci, ci, ci, ci, ci]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_get_tables.argtypes = [vp] + [vp] * 8
+        L.orc_max_keypoints.argtypes = [vp]
+        L.orc_extract.argtypes = [vp, vp, ci, vp, vp, vp]
+        L.orc_level_image.restype = vp
+        L.orc_level_image.argtypes = [vp, ci, ci]
+        L.orc_level_candidates.argtypes = [vp, ci, vp, vp, ci, vp, vp, vp]
+        L.orc_resize_bilinear.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci]
+        L.orc_gauss5.argtypes = [vp, ci, ci, ci, vp, ci]
+        L.orc_fast_detect.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp]
+        L.orc_fast_score.argtypes = [vp, ci, ci, ci, ci]
+        L.orc_fast_arc9.argtypes = [ci]
+        L.orc_distribute.argtypes = [ci, vp, vp, ci, ci, ci, vp, ci]
+        L.orc_ic_angle.restype = cf
+        L.orc_ic_angle.argtypes = [vp, ci, ci, ci, ci, ci]
+        L.orc_brief.argtypes = [vp, ci, ci, ci, ci, ci, cf, vp]
+        L.orc_atan2_deg.restype = cf
+        L.orc_atan2_deg.argtypes = [cf, cf]
+        L.orc_cos_sin_deg.argtypes = [cf, vp, vp]
+        L.orc_hamming.argtypes = [vp, vp]
+        L.orc_search_by_projection.argtypes = [vp, ci, vp, vp, vp, cf, ci, cf, cf, vp]
+        L.orc_search_by_bow.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp]
+        L.orc_assign_grid.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Extractor:
+    """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:52-130) on the CPU oracle."""
+
+    def __init__(self, nFeatures, nFastFeatures, scaleFactor, nLevels, iniThFAST, minThFAST, W, H):
+        self.L = lib()
+        self.h = self.L.orc_create(nFeatures, nFastFeatures, scaleFactor, nLevels, iniThFAST, minThFAST, W, H)
+        if not self.h:
+            raise ValueError("orc_create failed")
+        self.nLevels, self.W, self.H, self.nFast = nLevels, W, H, nFastFeatures
+        self.cap = self.L.orc_max_keypoints(self.h)
+        n = nLevels
+        self.scaleFactors = np.zeros(n, np.float32)
+        self.invScaleFactors = np.zeros(n, np.float32)
+        self.levelSigma2 = np.zeros(n, np.float32)
+        self.invLevelSigma2 = np.zeros(n, np.float32)
+        self.featuresPerLevel = np.zeros(n, np.int32)
+        self.umax = np.zeros(16, np.int32)
+        self.levelW = np.zeros(n, np.int32)
+        self.levelH = np.zeros(n, np.int32)
+        self.L.orc_get_tables(self.h, _p(self.scaleFactors), _p(self.invScaleFactors), _p(self.levelSigma2),
+                              _p(self.invLevelSigma2), _p(self.featuresPerLevel), _p(self.umax),
+                              _p(self.levelW), _p(self.levelH))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.H, self.W)
+        kp = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        per = np.zeros(self.nLevels, np.int32)
+        n = self.L.orc_extract(self.h, _p(img), img.strides[0], _p(kp), _p(desc), _p(per))
+        return kp[:n].copy(), desc[:n].copy(), per
+
+    def level_image(self, level, blurred=False):
+        ptr = self.L.orc_level_image(self.h, level, int(blurred))
+        w, h = int(self.levelW[level]), int(self.levelH[level])
+        buf = (C.c_uint8 * (w * h)).from_address(ptr)
+        return np.frombuffer(buf, np.uint8).reshape(h, w).copy()
+
+    def level_candidates(self, level):
+        cap = max(1, self.nFast)
+        xy = np.zeros((cap, 2), np.int16)
+        resp = np.zeros(cap, np.int32)
+        nh, ph, pl = C.c_int(), C.c_int(), C.c_int()
+        n = self.L.orc_level_candidates(self.h, level, _p(xy), _p(resp), cap, C.byref(nh), C.byref(ph), C.byref(pl))
+        return xy[:n].copy(), resp[:n].copy(), nh.value, ph.value, pl.value
+
+
+def resize_bilinear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_bilinear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gauss5(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().orc_gauss5(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast_detect(img, th, maxKp):
+    img = np.ascontiguousarray(img, np.uint8)
+    xy = np.zeros((max(1, maxKp), 2), np.int16)
+    resp = np.zeros(max(1, maxKp), np.int32)
+    pre = C.c_int()
+    n = lib().orc_fast_detect(_p(img), img.shape[1], img.shape[0], img.strides[0], th, maxKp, _p(xy), _p(resp), C.byref(pre))
+    return xy[:n].copy(), resp[:n].copy(), pre.value
+
+
+def fast_score(img, x, y, th):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_fast_score(_p(img), img.strides[0], x, y, th)
+
+
+def distribute(xy, resp, W, H, maxFeatures):
+    xy = np.ascontiguousarray(xy, np.int16)
+    resp = np.ascontiguousarray(resp, np.int32)
+    cap = max(maxFeatures + 16, 64) + 4 * max(1, int(round(W / H)))
+    sel = np.zeros(cap, np.int32)
+    n = lib().orc_distribute(len(resp), _p(xy), _p(resp), W, H, maxFeatures, _p(sel), cap)
+    return sel[:max(n, 0)].copy(), n
+
+
+def ic_angle(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_ic_angle(_p(img), img.shape[1], img.shape[0], img.strides[0], x, y)
+
+
+def brief(img, x, y, angle):
+    img = np.ascontiguousarray(img, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_brief(_p(img), img.shape[1], img.shape[0], img.strides[0], x, y, angle, _p(d))
+    return d
+
+
+def atan2_deg(m01, m10):
+    return lib().orc_atan2_deg(float(m01), float(m10))
+
+
+def cos_sin_deg(a):
+    c, s = C.c_float(), C.c_float()
+    lib().orc_cos_sin_deg(float(a), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_hamming(_p(a), _p(b))
+
+
+def make_frame_view(kp, desc, gridCols, gridRows, minX, minY, maxX, maxY, scaleFactors):
+    """Frame grid statics as src/Frame.cc:101-105 computes them."""
+    kp = np.ascontiguousarray(kp, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    sf = np.ascontiguousarray(scaleFactors, np.float32)
+    invw = np.float32(gridCols) / np.float32(np.float32(maxX) - np.float32(minX))
+    invh = np.float32(gridRows) / np.float32(np.float32(maxY) - np.float32(minY))
+    fv = FrameView(len(kp), kp.ctypes.data, desc.ctypes.data, gridCols, gridRows, minX, minY,
+                   float(invw), float(invh), len(sf), sf.ctypes.data)
+    fv._keep = (kp, desc, sf)
+    return fv
+
+
+def search_by_projection(fv, mps, mpDesc, initObs, th, nnRatio, bFarPoints=False, thFarPoints=0.0):
+    mps = np.ascontiguousarray(mps, MP_DTYPE)
+    mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+    out = np.zeros(max(1, fv.n), np.int32)
+    io = None if initObs is None else np.ascontiguousarray(initObs, np.int32)
+    n = lib().orc_search_by_projection(C.byref(fv), len(mps), _p(mps), _p(mpDesc), _p(io), th,
+                                       int(bFarPoints), thFarPoints, nnRatio, _p(out))
+    return n, out[:fv.n].copy()
+
+
+def assign_grid(fv):
+    out = np.zeros(max(1, fv.n), np.int32)
+    lib().orc_assign_grid(C.byref(fv), _p(out))
+    return out[:fv.n].copy()
+
+
+def search_by_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAngle, nnRatio, checkOrientation=True):
+    kfOff = np.ascontiguousarray(kfOff, np.int32)
+    kfIdx = np.ascontiguousarray(kfIdx, np.int32)
+    fOff = np.ascontiguousarray(fOff, np.int32)
+    fIdx = np.ascontiguousarray(fIdx, np.int32)
+    kfDesc = np.ascontiguousarray(kfDesc, np.uint8)
+    fDesc = np.ascontiguousarray(fDesc, np.uint8)
+    kfAngle = np.ascontiguousarray(kfAngle, np.float32)
+    fAngle = np.ascontiguousarray(fAngle, np.float32)
+    kfHasMP = np.ascontiguousarray(kfHasMP, np.uint8)
+    out = np.zeros(max(1, len(fDesc)), np.int32)
+    n = lib().orc_search_by_bow(len(kfOff) - 1, _p(kfOff), _p(kfIdx), _p(fOff), _p(fIdx), len(kfDesc),
+                                _p(kfDesc), _p(kfAngle), _p(kfHasMP), len(fDesc), _p(fDesc), _p(fAngle),
+                                nnRatio, int(checkOrientation), _p(out))
+    return n, out[:len(fDesc)].copy()
