@@ -333,18 +333,29 @@ void orc_gauss5(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int 
 {
     static const int k[5] = {22, 62, 88, 62, 22}; /* Q8, sum 256 (sigma 1.2) */
     int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)w * h);
-    for (int y = 0; y < h; y++)
+    int *rx = (int *)malloc(sizeof(int) * (size_t)(w + 4));
+    int *ry = (int *)malloc(sizeof(int) * (size_t)(h + 4));
+    for (int x = -2; x < w + 2; x++) rx[x + 2] = reflect101(x, w);
+    for (int y = -2; y < h + 2; y++) ry[y + 2] = reflect101(y, h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t *row = src + (size_t)y * spitch;
         for (int x = 0; x < w; x++) {
             int32_t s = 0;
-            for (int t = -2; t <= 2; t++) s += k[t + 2] * src[y * spitch + reflect101(x + t, w)];
+            for (int t = 0; t < 5; t++) s += k[t] * row[rx[x + t]];
             tmp[y * w + x] = s;
         }
-    for (int y = 0; y < h; y++)
+    }
+    for (int y = 0; y < h; y++) {
+        const int32_t *r0 = tmp + (size_t)ry[y] * w, *r1 = tmp + (size_t)ry[y + 1] * w,
+                      *r2 = tmp + (size_t)ry[y + 2] * w, *r3 = tmp + (size_t)ry[y + 3] * w,
+                      *r4 = tmp + (size_t)ry[y + 4] * w;
         for (int x = 0; x < w; x++) {
-            int32_t s = 0;
-            for (int t = -2; t <= 2; t++) s += k[t + 2] * tmp[reflect101(y + t, h) * w + x];
+            int32_t s = k[0] * r0[x] + k[1] * r1[x] + k[2] * r2[x] + k[3] * r3[x] + k[4] * r4[x];
             dst[y * dpitch + x] = (uint8_t)((s + 32768) >> 16);
         }
+    }
+    free(rx);
+    free(ry);
     free(tmp);
 }
 
@@ -383,7 +394,18 @@ static void calc_mask(const int ring[16], int v, int th, int *mask1, int *mask2)
     *mask2 = m2;
 }
 
-static int is_keypoint(int mask1, int mask2) { return orc_fast_arc9(mask1) || orc_fast_arc9(mask2); }
+/* same predicate as orc_fast_arc9 (checked exhaustively in tests/test_oracle_kat.py), branch-free */
+static inline int arc9_fast(unsigned m)
+{
+    unsigned m2 = m | (m << 16);
+    unsigned r = m2 & (m2 >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= m2 >> 8;
+    return (r & 0xffffu) != 0;
+}
+
+static int is_keypoint(int mask1, int mask2) { return arc9_fast((unsigned)mask1) || arc9_fast((unsigned)mask2); }
 
 /* cornerScore, Fast_gpu.cu:193-216: binary search for the largest threshold still a corner */
 static int corner_score(const int ring[16], int v, int threshold)
@@ -404,8 +426,14 @@ static int corner_score(const int ring[16], int v, int threshold)
 int orc_fast_score(const uint8_t *img, int pitch, int x, int y, int threshold)
 {
     int ring[16];
-    for (int k = 0; k < 16; k++) ring[k] = img[(y + k_ring_dy[k]) * pitch + x + k_ring_dx[k]];
     int v = img[y * pitch + x];
+    {
+        /* isKeyPoint2's early reject (Fast_gpu.cu:237-245): ring bits 4 and 12 are an opposite
+         * pair, every 9-arc holds one of them */
+        const int e = img[y * pitch + x + 3] - v, w_ = img[y * pitch + x - 3] - v;
+        if (!(e < -threshold || e > threshold || w_ < -threshold || w_ > threshold)) return 0;
+    }
+    for (int k = 0; k < 16; k++) ring[k] = img[(y + k_ring_dy[k]) * pitch + x + k_ring_dx[k]];
     int m1, m2;
     calc_mask(ring, v, threshold, &m1, &m2);
     if (!is_keypoint(m1, m2)) return 0;
