@@ -132,7 +132,7 @@ int orbfe_debug_get_candidates(orbfe_handle *h, int frame, int level, uint32_t *
  * orbfe_get_stage_ms() synchronises on the recorded events and returns, per stage in the order of
  * orbfe_stage_name(), the SUM of elapsed milliseconds over the recorded calls; *n_calls receives
  * how many calls were summed (<= 128).  The last stage is the whole chain ("total"). */
-#define ORBFE_NUM_STAGES 6
+#define ORBFE_NUM_STAGES 5
 int orbfe_set_stage_timing(orbfe_handle *h, int enabled);
 int orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_NUM_STAGES], int *n_calls);
 const char *orbfe_stage_name(int stage);
@@ -182,6 +182,21 @@ int orbfe_match_projection(orbfe_handle *h, const orbfe_frame_view *frame, int n
                            const orbfe_map_point *map_points, const uint8_t *mp_desc,
                            const int *init_obs, float th, int far_points, float th_far_points,
                            float nn_ratio, int *match_out, int *n_matches);
+
+/* Batched, HBM-resident form of the same function (no reference analogue; BASELINE configs 2/3):
+ * frame b's keypoints / descriptors / counts are the outputs of orbfe_extract_batch_device
+ * (stride kp_stride == orbfe_max_keypoints()), its map points are d_map_points[b*n_map_points ..],
+ * scale factors are the handle's own mvScaleFactor.  All d_* pointers are device pointers;
+ * d_init_obs may be NULL.  Work is queued on `stream`; the call synchronises the stream once per
+ * pair of fixed-point iterations to test convergence, so it returns with the results complete. */
+int orbfe_match_projection_batch_device(orbfe_handle *h, int batch, const orbfe_keypoint *d_kp,
+                                        const uint8_t *d_desc, const int *d_n, int kp_stride,
+                                        int grid_cols, int grid_rows, float min_x, float min_y,
+                                        float grid_inv_w, float grid_inv_h, int n_map_points,
+                                        const orbfe_map_point *d_map_points, const uint8_t *d_mp_desc,
+                                        const int *d_init_obs, float th, int far_points,
+                                        float th_far_points, float nn_ratio, int *d_match_out,
+                                        int *d_n_matches, void *stream);
 
 /* replaces ORBmatcher::SearchByBoW(KeyFrame, Frame, matches, nnRatio, checkOrientation)
  * (src/ORBmatcher.cc:133-327; caller src/Tracking.cc:835), mono.  The merge-walk over the two

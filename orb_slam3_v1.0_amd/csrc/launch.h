@@ -6,17 +6,14 @@ namespace orbfe {
 
 // kernels_pyramid.hip
 void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFrameStride, int sw, int sh,
-                   int spitch, uint8_t* dst, size_t dstFrameStride, int dw, int dh, int dpitch,
+                   int spitch, int srcAligned4, uint8_t* dst, size_t dstFrameStride, int dw, int dh, int dpitch,
                    const uint32_t* xtab, const uint32_t* ytab);
-int blur_tiles_for(int w, int h);
-void launch_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
-                 size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const int* dBlurTileBase);
 
-// kernels_fast.hip
+// kernels_fast.hip (FAST + NMS + compaction fused with the Gaussian blur of the same tile)
 void fast_tiles_for(int w, int h, int* tx, int* ty);
-void launch_fast(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
-                 size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws, uint32_t* cand,
-                 uint32_t* counters);
+void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
+                      size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws, uint32_t* cand,
+                      uint32_t* counters);
 
 // kernels_quadtree.hip
 int quadtree_node_capacity(int variant);

@@ -21,6 +21,13 @@ int match_projection_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view*
                          int farPoints, float thFar, float nnRatio, int* matchOut, int* nMatches,
                          std::string& err);
 
+int match_projection_batch_device(MatchScratch& m, hipStream_t s, int B, const orbfe_keypoint* dKp, const uint8_t* dDesc,
+                                  const int* dN, int kpStride, int gridCols, int gridRows, float minX, float minY,
+                                  float invW, float invH, const float* dScaleFactors, int nLevels, int M,
+                                  const orbfe_map_point* dMps, const uint8_t* dMpDesc, const int* dInitObs, float th,
+                                  int farPoints, float thFar, float nnRatio, int* dMatchOut, int* dNMatches,
+                                  std::string& err);
+
 int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const int* kfIdx, const int* fOff,
                   const int* fIdx, int nKF, const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfHasMP,
                   int nF, const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation,

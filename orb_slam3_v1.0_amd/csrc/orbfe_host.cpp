@@ -25,7 +25,7 @@ constexpr int kEventSets = 128;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-const char* kStageNames[ORBFE_NUM_STAGES] = {"pyramid_resize", "gauss_blur", "fast_nms",
+const char* kStageNames[ORBFE_NUM_STAGES] = {"pyramid_resize", "fast_nms_blur",
                                              "quadtree", "orient_brief", "total"};
 
 }  // namespace
@@ -40,7 +40,6 @@ struct orbfe_handle {
     PipelineDesc* dP = nullptr;
     int maxBatch = 1;
     int maxNodeCap = 0;
-    int blurTotalTiles = 0;
 
     uint8_t* ws = nullptr;          // pyramid + blurred pyramid, all frames
     size_t wsBytes = 0;
@@ -50,7 +49,7 @@ struct orbfe_handle {
     uint32_t* dCounters = nullptr;  // [frame][level][kCntWords]
     uint32_t* dLvlKp = nullptr;     // [frame][kpCapFrame]
     uint32_t* dTabs = nullptr;      // resize tables
-    int* dBlurTileBase = nullptr;
+    float* dSf = nullptr;           // mvScaleFactor on the device (batched matcher)
 
     // staging for the host-pointer API
     uint8_t* dIn = nullptr;
@@ -121,7 +120,7 @@ void destroy_impl(orbfe_handle* h)
             if (e) (void)hipEventDestroy(e);
     match_scratch_free(h->match);
     void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTabs,
-                     h->dBlurTileBase, h->dIn, h->dKp, h->dDesc, h->dN, h->dPer};
+                     h->dSf, h->dIn, h->dKp, h->dDesc, h->dN, h->dPer};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     void* hptrs[] = {h->hIn, h->hKp, h->hDesc, h->hN, h->hPer, h->hCounters};
@@ -216,8 +215,7 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     P.iniTh = p->ini_th_fast;
     P.minTh = p->min_th_fast;
     size_t wsOff = 0, candOff = 0, tabOff = 0;
-    int tileBase = 0, kpBase = 0, blurTiles = 0;
-    std::vector<int> blurTileBase(nL + 1, 0);
+    int tileBase = 0, kpBase = 0;
     const size_t B = (size_t)p->max_batch;
     int status = ORBFE_OK;
     for (int l = 0; l < nL; l++) {
@@ -255,15 +253,13 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
         wsOff += frameBytes * B;
         L.candOff = candOff;
         candOff += (size_t)L.candCap * B;
+        tabOff = align_up(tabOff, 4);  // uint4 table loads in resize_kernel
         L.xtabOff = tabOff;
-        tabOff += (size_t)L.w;
+        tabOff += align_up((size_t)L.w, 4);
         L.ytabOff = tabOff;
-        tabOff += (size_t)L.h;
-        blurTileBase[l] = blurTiles;
-        blurTiles += blur_tiles_for(L.w, L.h);
+        tabOff += align_up((size_t)L.h, 4);
         h->maxNodeCap = std::max(h->maxNodeCap, L.nodeCap);
     }
-    blurTileBase[nL] = blurTiles;
     if (status == ORBFE_OK && h->maxNodeCap > quadtree_node_capacity(1)) status = ORBFE_ERR_UNSUPPORTED;
     if (status != ORBFE_OK) {
         delete h;
@@ -271,7 +267,6 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     }
     P.kpCapFrame = kpBase;
     P.totalTiles = tileBase;
-    h->blurTotalTiles = blurTiles;
     h->wsBytes = wsOff;
     h->candWordsPerBatch = candOff;
 
@@ -299,10 +294,10 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     CREATE_CHK(hipMalloc(&h->dCounters, B * nL * kCntWords * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dLvlKp, B * (size_t)P.kpCapFrame * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dTabs, tabs.size() * sizeof(uint32_t)));
-    CREATE_CHK(hipMalloc(&h->dBlurTileBase, (nL + 1) * sizeof(int)));
+    CREATE_CHK(hipMalloc(&h->dSf, kMaxLevels * sizeof(float)));
+    CREATE_CHK(hipMemcpy(h->dSf, h->sf, kMaxLevels * sizeof(float), hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(h->dP, &P, sizeof P, hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(h->dTabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    CREATE_CHK(hipMemcpy(h->dBlurTileBase, blurTileBase.data(), (nL + 1) * sizeof(int), hipMemcpyHostToDevice));
 
     // staging for the host-pointer entry points
     h->dInPitch = (int)align_up((size_t)p->image_width, kPitchAlign);
@@ -415,19 +410,17 @@ int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t fr
         const uint8_t* src = l == 1 ? d_gray : h->ws + S.imgOff;
         const size_t sstride = l == 1 ? frame_stride : S.imgFrameStride;
         const int spitch = l == 1 ? pitch : S.pitch;
-        launch_resize(s, batch, src, sstride, S.w, S.h, spitch, h->ws + D.imgOff, D.imgFrameStride, D.w, D.h,
+        launch_resize(s, batch, src, sstride, S.w, S.h, spitch, l == 1 ? aligned4 : 1, h->ws + D.imgOff, D.imgFrameStride, D.w, D.h,
                       D.pitch, h->dTabs + D.xtabOff, h->dTabs + D.ytabOff);
     }
     if (ev) HIPCHK(h, hipEventRecord(ev[1], s));
-    launch_blur(s, batch, h->blurTotalTiles, h->dP, d_gray, frame_stride, pitch, h->ws, h->dBlurTileBase);
+    launch_fast_blur(s, batch, P.totalTiles, h->dP, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters);
     if (ev) HIPCHK(h, hipEventRecord(ev[2], s));
-    launch_fast(s, batch, P.totalTiles, h->dP, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters);
-    if (ev) HIPCHK(h, hipEventRecord(ev[3], s));
     launch_quadtree(s, batch, nL, h->maxNodeCap, h->dP, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp);
-    if (ev) HIPCHK(h, hipEventRecord(ev[4], s));
+    if (ev) HIPCHK(h, hipEventRecord(ev[3], s));
     launch_orient_brief(s, batch, P.kpCapFrame, h->dP, d_gray, frame_stride, pitch, h->ws, h->dCounters, h->dLvlKp,
                         d_kp, d_desc, d_n, d_per);
-    if (ev) HIPCHK(h, hipEventRecord(ev[5], s));
+    if (ev) HIPCHK(h, hipEventRecord(ev[4], s));
     HIPCHK(h, hipGetLastError());
     h->lastGray = d_gray;
     h->lastStride = frame_stride;
@@ -569,6 +562,27 @@ int orbfe_match_projection(orbfe_handle* h, const orbfe_frame_view* F, int M, co
     std::string err;
     int rc = match_projection_run(h->match, h->stream, F, M, mps, mp_desc, init_obs, th, far_points, th_far, nn_ratio,
                                   match_out, n_matches, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+int orbfe_match_projection_batch_device(orbfe_handle* h, int batch, const orbfe_keypoint* d_kp, const uint8_t* d_desc,
+                                        const int* d_n, int kp_stride, int grid_cols, int grid_rows, float min_x,
+                                        float min_y, float inv_w, float inv_h, int M, const orbfe_map_point* d_mps,
+                                        const uint8_t* d_mp_desc, const int* d_init_obs, float th, int far_points,
+                                        float th_far, float nn_ratio, int* d_match_out, int* d_n_matches, void* stream_)
+{
+    if (!h || !d_kp || !d_desc || !d_n || !d_match_out || !d_n_matches || batch < 1 || M < 0 || kp_stride < 1 ||
+        grid_cols < 1 || grid_rows < 1)
+        return ORBFE_ERR_INVALID_ARG;
+    if (M > 0 && (!d_mps || !d_mp_desc)) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
+    std::string err;
+    int rc = match_projection_batch_device(h->match, s, batch, d_kp, d_desc, d_n, kp_stride, grid_cols, grid_rows, min_x,
+                                           min_y, inv_w, inv_h, h->dSf, h->nLevels, M, d_mps, d_mp_desc, d_init_obs, th,
+                                           far_points, th_far, nn_ratio, d_match_out, d_n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
 }

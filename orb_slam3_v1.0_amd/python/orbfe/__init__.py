@@ -19,7 +19,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<i4"), ("size", "
                      ("octave", "<i4"), ("angle", "<f4")])
 MP_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("view_cos", "<f4"), ("track_depth", "<f4"),
                      ("level", "<i4"), ("in_view", "<i4"), ("bad", "<i4"), ("observations", "<i4")])
-NUM_STAGES = 6
+NUM_STAGES = 5
 
 STATUS = {0: "ORBFE_OK", 1: "ORBFE_ERR_INVALID_ARG", 2: "ORBFE_ERR_UNSUPPORTED", 3: "ORBFE_ERR_NO_DEVICE",
           4: "ORBFE_ERR_HIP", 5: "ORBFE_ERR_OUT_OF_MEMORY", 6: "ORBFE_ERR_INTERNAL"}
@@ -51,10 +51,27 @@ SYMBOLS = [
     "orbfe_get_level_info", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
-    "orbfe_match_projection", "orbfe_match_bow", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+    libamdhip64.so.7, looked up by file name through $ORIGIN); if liborbfe.so pulled in the system
+    copy first, a later `import torch` would load a second HIP/HSA runtime that sees no GPU and
+    whose streams are foreign to ours.  Loading torch's copy first makes liborbfe.so bind to it."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
 
 
 def lib():
@@ -65,6 +82,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("liborbfe.so not found at %s -- run __graft_entry__.build() (hipcc, gfx950); "
                            "there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.orbfe_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
@@ -87,6 +105,8 @@ def lib():
     L.orbfe_stage_name.restype = C.c_char_p
     L.orbfe_hamming.argtypes = [vp, vp]
     L.orbfe_match_projection.argtypes = [vp, C.POINTER(FrameView), ci, vp, vp, vp, cf, ci, cf, cf, vp, vp]
+    L.orbfe_match_projection_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp,
+                                                      cf, ci, cf, cf, vp, vp, vp]
     L.orbfe_match_bow.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp, vp]
     L.orbfe_status_string.argtypes = [ci]
     L.orbfe_status_string.restype = C.c_char_p
@@ -260,6 +280,17 @@ class ORBmatcher:
                                                   int(bFarPoints), thFarPoints, nnRatio, _p(out), C.byref(n)),
                     "orbfe_match_projection")
         return n.value, out[:fv.n].copy()
+
+    def SearchByProjection_batch_device(self, batch, d_kp, d_desc, d_n, kp_stride, gridCols, gridRows, minX, minY,
+                                        maxX, maxY, M, d_mps, d_mp_desc, d_init_obs, th, nnRatio, d_match_out,
+                                        d_n_matches, bFarPoints=False, thFarPoints=0.0, stream=None):
+        """Batched HBM-resident SearchByProjection; all d_* are raw device pointers (ints)."""
+        invw = float(np.float32(gridCols) / np.float32(np.float32(maxX) - np.float32(minX)))
+        invh = float(np.float32(gridRows) / np.float32(np.float32(maxY) - np.float32(minY)))
+        self.e._chk(self.L.orbfe_match_projection_batch_device(
+            self.e.h, batch, d_kp, d_desc, d_n, kp_stride, gridCols, gridRows, minX, minY, invw, invh, M, d_mps,
+            d_mp_desc, d_init_obs, th, int(bFarPoints), thFarPoints, nnRatio, d_match_out, d_n_matches, stream),
+            "orbfe_match_projection_batch_device")
 
     def SearchByBoW(self, kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAngle, nnRatio,
                     checkOrientation=True):

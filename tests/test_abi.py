@@ -1,0 +1,58 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/orbfe.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "orbfe.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbfe_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(built):
+    import orbfe
+    L = orbfe.lib()
+    decl = _declared()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(L, name), "liborbfe.so does not export %s" % name
+    assert sorted(orbfe.SYMBOLS) == decl, "python binding and header disagree"
+
+
+def test_host_only_entry_points(built):
+    import orbfe
+    L = orbfe.lib()
+    assert b"gfx950" in L.orbfe_version()
+    assert L.orbfe_status_string(0) == b"ok" and L.orbfe_status_string(3).startswith(b"no usable")
+    a = np.arange(32, dtype=np.uint8)
+    b = a[::-1].copy()
+    assert orbfe.ORBmatcher.DescriptorDistance(a, b) == int(np.unpackbits(a ^ b).sum())
+    assert [L.orbfe_stage_name(i) for i in range(5)][-1] == b"total"
+
+
+def test_create_fails_loudly_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import orbfe
+    with pytest.raises(orbfe.OrbfeError) as ei:
+        orbfe.ORBextractor(1000, 16000, 1.2, 8, 20, 7, 752, 480)
+    assert ei.value.code == 3  # ORBFE_ERR_NO_DEVICE: no CPU fallback exists
+
+
+def test_create_rejects_bad_arguments(built):
+    import orbfe
+    L = orbfe.lib()
+    h = C.c_void_p()
+    assert L.orbfe_create(None, C.byref(h)) == 1
+    bad = orbfe.Params(1000, 16000, 1.2, 0, 20, 7, 752, 480, 0, 1)
+    assert L.orbfe_create(C.byref(bad), C.byref(h)) == 1
+    bad = orbfe.Params(1000, 16000, 1.2, 8, 5, 7, 752, 480, 0, 1)  # iniTh < minTh: unsupported by the fused pass
+    assert L.orbfe_create(C.byref(bad), C.byref(h)) == 2
+    assert L.orbfe_max_keypoints(None) == 0 and L.orbfe_get_levels(None) == 0
