@@ -18,6 +18,15 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i < n ? i : p - i;
 }
 
+// REFLECT_101 for overshoots smaller than n (one bounce, no modulo), clamped so that the result is
+// always a valid index even in a caller's don't-care region
+__device__ __forceinline__ int reflect_near(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
 __device__ __forceinline__ float spec_atan2f(float y, float x)
 {
     const float kPi = 0x1.921fb6p+1f, kPi2 = 0x1.921fb6p+0f, kPi4 = 0x1.921fb6p-1f;

@@ -88,19 +88,20 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     // ---- IC angle ----
     const int u = (lane & 31) - kHalfPatch;   // -15..16 (16 == idle lane 31/63)
     const int sgn = (lane < 32) ? 1 : -1;
-    const bool interior = x >= kHalfPatch && x + kHalfPatch < w && y >= kHalfPatch && y + kHalfPatch < h;
-    const int cx = interior ? x + u : reflect101(x + u, w);
+    // every level is >= 16 px and keypoints sit >= 6 px inside, so one reflection suffices
+    const int cx = reflect_near(x + u, w);
+    int vals[kHalfPatch + 1];
+#pragma unroll
+    for (int v = 0; v <= kHalfPatch; v++)  // 16 independent loads in flight
+        vals[v] = img[(size_t)reflect_near(y + sgn * v, h) * ipitch + cx];
     int m10 = 0, m01 = 0;
-#pragma unroll 4
+    const int au = abs(u);
+#pragma unroll
     for (int v = 0; v <= kHalfPatch; v++) {
-        const bool act = (u <= kHalfPatch) && (abs(u) <= c_umax[v]) && !(v == 0 && sgn < 0);
-        if (act) {
-            const int yy = y + sgn * v;
-            const int ry = interior ? yy : reflect101(yy, h);
-            const int val = img[(size_t)ry * ipitch + cx];
-            m10 += u * val;
-            m01 += sgn * v * val;
-        }
+        const bool act = (au <= c_umax[v]) && !(v == 0 && sgn < 0);  // c_umax <= 15 masks the idle lane (u == 16)
+        const int val = act ? vals[v] : 0;
+        m10 += u * val;
+        m01 += sgn * v * val;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
@@ -109,10 +110,9 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     // ---- steered BRIEF ----
     float a, b;
     cos_sin_deg(angle, a, b);
-    const bool binterior = x >= 19 && x + 19 < w && y >= 19 && y + 19 < h;  // rotated reach <= 18.4 px
-    unsigned long long bits[4];
+    int t0[4], t1[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 4; q++) {  // 8 independent sample loads in flight (rotated reach <= 18.4 px)
         const int pair = q * 64 + lane;
         const int8_t* pt = &c_pattern[pair * 4];
         const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
@@ -120,16 +120,14 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
         float c0 = x0 * a; const float c0b = y0 * b; c0 = c0 - c0b;
         float r1 = x1 * b; const float r1b = y1 * a; r1 = r1 + r1b;
         float c1 = x1 * a; const float c1b = y1 * b; c1 = c1 - c1b;
-        int ya = y + __float2int_rn(r0), xa = x + __float2int_rn(c0);
-        int yb = y + __float2int_rn(r1), xb = x + __float2int_rn(c1);
-        if (!binterior) {
-            ya = reflect101(ya, h); xa = reflect101(xa, w);
-            yb = reflect101(yb, h); xb = reflect101(xb, w);
-        }
-        const int t0 = blur[(size_t)ya * bpitch + xa];
-        const int t1 = blur[(size_t)yb * bpitch + xb];
-        bits[q] = __ballot(t0 < t1);
+        const int ya = reflect_near(y + __float2int_rn(r0), h), xa = reflect_near(x + __float2int_rn(c0), w);
+        const int yb = reflect_near(y + __float2int_rn(r1), h), xb = reflect_near(x + __float2int_rn(c1), w);
+        t0[q] = blur[(size_t)ya * bpitch + xa];
+        t1[q] = blur[(size_t)yb * bpitch + xb];
     }
+    unsigned long long bits[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bits[q] = __ballot(t0[q] < t1[q]);
 
     // ---- outputs: 24-byte keypoint (6 dwords) + 32-byte descriptor (4 qwords) ----
     orbfe_keypoint* ko = kpOut + (size_t)f * P->kpCapFrame + slot;

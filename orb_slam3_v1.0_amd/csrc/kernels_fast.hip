@@ -27,7 +27,10 @@
 // Candidate order in HBM is not deterministic (one atomicAdd per block reserves the slots) -- every
 // consumer is order-independent: it uses the raster key (y, x) carried in the word (S2b).
 // Algorithmic bytes per pixel: 1 read (level) + 1 written (blurred level) + 4 per candidate.
+#include <cstdlib>
+
 #include "launch.h"
+#include "device_math.h"
 
 namespace orbfe {
 
@@ -65,15 +68,17 @@ __device__ __forceinline__ int arc_max_min(const int (&a)[16])
     return best;
 }
 
-// stage A: compass points = ring bits 0 (+3,0), 4 (0,+3), 8 (-3,0), 12 (0,-3).  A 9-arc always
-// holds two adjacent compass points, so fewer than two bright (or dark) ones => not a corner.
-__device__ __forceinline__ bool compass_pass(const uint8_t (*img)[kImgW], int r, int c, int th)
+// stage A: compass points = ring bits 0 (+3,0), 4 (0,+3), 8 (-3,0), 12 (0,-3).  Nine consecutive
+// ring positions always contain two ADJACENT compass points (consecutive multiples of 4), so a
+// corner needs an adjacent compass pair that is bright (both > th) or dark (both < -th).
+// `p` points at the centre pixel inside the staged tile (row pitch kImgW).
+__device__ __forceinline__ bool compass_pass_ptr(const uint8_t* p, int th)
 {
-    const int v = img[r][c];
-    const int d0 = img[r + 3][c] - v, d4 = img[r][c + 3] - v, d8 = img[r - 3][c] - v, d12 = img[r][c - 3] - v;
-    const int nb = (d0 > th) + (d4 > th) + (d8 > th) + (d12 > th);
-    const int nd = (d0 < -th) + (d4 < -th) + (d8 < -th) + (d12 < -th);
-    return nb >= 2 || nd >= 2;
+    const int v = p[0];
+    const int d0 = p[3 * kImgW] - v, d4 = p[3] - v, d8 = p[-3 * kImgW] - v, d12 = p[-3] - v;
+    const int hiPair = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
+    const int loPair = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+    return hiPair > th || loPair < -th;
 }
 
 __device__ __forceinline__ void ring_diffs(const uint8_t (*img)[kImgW], int r, int c, int (&d)[16])
@@ -87,8 +92,8 @@ __device__ __forceinline__ void ring_diffs(const uint8_t (*img)[kImgW], int r, i
     d[15] = img[r + 3][c - 1] - v;
 }
 
-// stage B: full 16-pixel segment test at threshold th
-__device__ __forceinline__ bool segment_test(const int (&d)[16], int th)
+// stage B: full 16-pixel segment test at threshold th; bit 0 = bright 9-arc, bit 1 = dark 9-arc
+__device__ __forceinline__ uint32_t segment_test(const int (&d)[16], int th)
 {
     uint32_t mb = 0, md = 0;
 #pragma unroll
@@ -96,17 +101,26 @@ __device__ __forceinline__ bool segment_test(const int (&d)[16], int th)
         mb |= (uint32_t)(d[k] > th) << k;
         md |= (uint32_t)(d[k] < -th) << k;
     }
-    return arc9(mb) || arc9(md);
+    return (uint32_t)arc9(mb) | ((uint32_t)arc9(md) << 1);
 }
 
 // stage C: largest t such that some 9-arc has all |diff| > t  ==  max-min over arcs, minus 1
-// (equals the binary search of cornerScore, Fast_gpu.cu:193-216)
-__device__ __forceinline__ int corner_score(const int (&d)[16])
+// (equals the binary search of cornerScore, Fast_gpu.cu:193-216).  A polarity without a 9-arc at
+// `th` has max-min <= th < the other polarity's, so only polarities that pass arc9 are evaluated
+// (both pass only for exotic rings).
+__device__ __forceinline__ int corner_score(const int (&d)[16], bool pb, bool pd)
 {
-    int nd_[16];
+    const int sgn = pb ? 1 : -1;
+    int a[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) nd_[k] = -d[k];
-    return max(arc_max_min(d), arc_max_min(nd_)) - 1;
+    for (int k = 0; k < 16; k++) a[k] = sgn * d[k];
+    int best = arc_max_min(a);
+    if (pb && pd) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[k] = -d[k];
+        best = max(best, arc_max_min(a));
+    }
+    return best - 1;
 }
 
 // append `flag`ged lanes' value to an LDS queue (one LDS atomic per wave)
@@ -120,14 +134,9 @@ __device__ __forceinline__ void queue_push(bool flag, uint16_t value, uint16_t* 
     if (flag) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
-// REFLECT_101 for small overshoots (|overshoot| < n), clamped for the don't-care region far outside
-__device__ __forceinline__ int reflect_near(int i, int n)
-{
-    i = i < 0 ? -i : i;
-    i = i >= n ? 2 * n - 2 - i : i;
-    return min(max(i, 0), n - 1);
-}
-
+// MODE is a timing-only ablation switch (ORBFE_FAST_MODE env var): bit 0 = Gaussian, bit 1 = FAST;
+// the product always runs MODE 3.
+template <int MODE>
 __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __restrict__ P,
                                                         const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
                                                         int gray0Pitch, int gray0Aligned4,
@@ -136,7 +145,8 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
 {
     __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH][kImgW];
     __shared__ __attribute__((aligned(16))) uint16_t sTmp[kTmpH][kFastTW];
-    __shared__ uint8_t sScore[kScH][kScPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH][kScPitch];
+    __shared__ uint32_t sCnt4[4];  // per-wave totals of the stage-A scan
     __shared__ uint32_t sCand[kMaxTileCand];
     __shared__ uint32_t sCnt[4];  // tile: survivors, high survivors, pre-NMS low, pre-NMS high
     __shared__ uint32_t sBase;
@@ -194,6 +204,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     }
     __syncthreads();
 
+    if constexpr ((MODE & 1) != 0) {
     // ================= Gaussian 5x5 of the tile (S1) =================
     // horizontal: output column xl (0..63) of row rr (image row y0-2+rr) taps LDS cols xl+2..xl+6
     for (int e = tid; e < kTmpH * (kFastTW / 4); e += 256) {
@@ -251,35 +262,71 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         }
     }
 
+    }  // MODE & 1
+
+    if constexpr ((MODE & 2) != 0) {
     // ================= FAST =================
     // tested region 6 <= x <= w-6, 6 <= y <= h-6 (Fast_gpu.cu:275,365-368: strict compares
     // against border 5 and dim-5); scores are needed for the tile + 1-px halo (NMS)
-    // stage A: compass test on every position, survivors -> queue A; scores default to 0
-    constexpr int kPos = kScH * kScW;
-    constexpr int kIterA = (kPos + 255) / 256;
-#pragma unroll 1
-    for (int it = 0; it < kIterA; it++) {  // uniform trip count: queue_push uses wave ballots
-        const int e = tid + it * 256;
-        bool pass = false;
-        if (e < kPos) {
-            const int sy = e / kScW;
-            const int sx = e - sy * kScW;
-            const int px = x0 - 1 + sx, py = y0 - 1 + sy;
-            sScore[sy][sx] = 0;
-            if (px > kEdge && px < w - kEdge && py > kEdge && py < h - kEdge)
-                pass = compass_pass(sImg, sy + 3, sx + 3, minTh);
+    // stage A: compass test on every position, survivors -> queue A; scores default to 0.
+    // Column strips: lane = score column, the 4 waves split the 34 score rows (9,9,8,8); LDS reads
+    // use immediate offsets from one running pointer, pass flags accumulate in a per-lane bit mask
+    // and ONE block scan compacts them.  Score columns 64,65 (right halo) take one extra
+    // evaluation on threads 0..67 (bit 9 of the mask).
+    for (int e = tid; e < kScH * (kScPitch / 4); e += 256) reinterpret_cast<uint32_t*>(&sScore[0][0])[e] = 0;
+    uint32_t passMask = 0;
+    const int wv = tid >> 6;
+    const int syBeg = wv * 9 - (wv > 2 ? wv - 2 : 0);  // 0, 9, 18, 26
+    const int syEnd = min(syBeg + (wv < 2 ? 9 : 8), kScH);
+    {
+        const int px = x0 - 1 + lane;
+        const bool xok = px > kEdge && px < w - kEdge;
+        // rows whose py is outside (kEdge, h-kEdge) are skipped wave-uniformly
+        const int lo = max(syBeg, kEdge + 2 - y0);          // py = y0-1+sy > kEdge
+        const int hi = min(syEnd, h - kEdge + 1 - y0);      // py < h-kEdge
+        const uint8_t* p = &sImg[lo + 3][lane + 3];
+        for (int sy = lo; sy < hi; sy++, p += kImgW)
+            passMask |= (uint32_t)(xok && compass_pass_ptr(p, minTh)) << (sy - syBeg);
+    }
+    if (tid < 2 * kScH) {
+        const int sy = tid >> 1, sx = kFastTW + (tid & 1);
+        const int px = x0 - 1 + sx, py = y0 - 1 + sy;
+        if (px > kEdge && px < w - kEdge && py > kEdge && py < h - kEdge)
+            passMask |= (uint32_t)compass_pass_ptr(&sImg[sy + 3][sx + 3], minTh) << 9;
+    }
+    {
+        // block-wide exclusive scan of popc(passMask) -> queue offsets
+        const int cntA = __popc(passMask);
+        int incl = cntA;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int o = __shfl_up(incl, dlt);
+            if (lane >= dlt) incl += o;
         }
-        queue_push(pass, (uint16_t)e, sQA, &sQ[0], lane);
+        if (lane == 63) sCnt4[wv] = (uint32_t)incl;
+        __syncthreads();
+        int base = incl - cntA;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < wv) base += (int)sCnt4[q];
+        if (tid == 255) sQ[0] = (uint32_t)(base + cntA);
+        uint32_t m = passMask;
+        while (m) {
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            const int e = b < 9 ? (syBeg + b) * kScW + lane : (tid >> 1) * kScW + kFastTW + (tid & 1);
+            sQA[base++] = (uint16_t)e;
+        }
     }
     __syncthreads();
     // stage B: full segment test on queue A (dense), corners -> queue B
-    {
+    if constexpr ((MODE & 4) == 0) {
         const int nA = (int)sQ[0];
         const int itB = (nA + 255) / 256;
 #pragma unroll 1
         for (int it = 0; it < itB; it++) {
             const int i = tid + it * 256;
-            bool corner = false;
+            uint32_t pol = 0;
             uint16_t e = 0;
             if (i < nA) {
                 e = sQA[i];
@@ -287,57 +334,71 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                 const int sx = e - sy * kScW;
                 int d[16];
                 ring_diffs(sImg, sy + 3, sx + 3, d);
-                corner = segment_test(d, minTh);
+                pol = segment_test(d, minTh);
             }
-            queue_push(corner, e, sQB, &sQ[1], lane);
+            queue_push(pol != 0, (uint16_t)(e | (pol << 12)), sQB, &sQ[1], lane);  // e < 2244 < 4096
         }
     }
     __syncthreads();
     // stage C: corner score on queue B (dense)
+    const int nB = (MODE & 8) ? 0 : (int)sQ[1];
+    for (int i = tid; i < nB; i += 256) {
+        const uint32_t q = sQB[i];
+        const int e = (int)(q & 0xfffu);
+        const int sy = e / kScW;
+        const int sx = e - sy * kScW;
+        int d[16];
+        ring_diffs(sImg, sy + 3, sx + 3, d);
+        sScore[sy][sx] = (uint8_t)corner_score(d, (q & 0x1000u) != 0, (q & 0x2000u) != 0);
+    }
+    __syncthreads();
+
+    // ---- NMS (strictly greater than all 8 neighbours, Fast_gpu.cu:300-310) + tile compaction,
+    //      again over the dense corner queue; halo corners only serve as neighbours ----
     {
-        const int nB = (int)sQ[1];
-        for (int i = tid; i < nB; i += 256) {
-            const int e = sQB[i];
-            const int sy = e / kScW;
-            const int sx = e - sy * kScW;
-            int d[16];
-            ring_diffs(sImg, sy + 3, sx + 3, d);
-            sScore[sy][sx] = (uint8_t)corner_score(d);
+        const int itN = (nB + 255) / 256;
+#pragma unroll 1
+        for (int it = 0; it < itN; it++) {
+            const int i = tid + it * 256;
+            bool pre = false, keep = false, hi = false;
+            int ox = 0, oy = 0, s = 0;
+            if (i < nB) {
+                const int e = (int)(sQB[i] & 0xfffu);
+                const int sy = e / kScW;
+                const int sx = e - sy * kScW;
+                ox = sx - 1;
+                oy = sy - 1;
+                pre = ox >= 0 && ox < kFastTW && oy >= 0 && oy < kFastTH;  // interior: counted once
+                if (pre) {
+                    s = sScore[sy][sx];
+                    hi = s >= iniTh;
+                    keep = s > sScore[sy - 1][sx - 1] && s > sScore[sy - 1][sx] && s > sScore[sy - 1][sx + 1] &&
+                           s > sScore[sy][sx - 1] && s > sScore[sy][sx + 1] && s > sScore[sy + 1][sx - 1] &&
+                           s > sScore[sy + 1][sx] && s > sScore[sy + 1][sx + 1];
+                }
+            }
+            const unsigned long long mPre = __ballot(pre);
+            if (mPre == 0) continue;  // wave-uniform
+            const unsigned long long mPreHi = __ballot(pre && hi);
+            const unsigned long long mKeep = __ballot(keep);
+            const unsigned long long mKeepHi = __ballot(keep && hi);
+            uint32_t wbase = 0;
+            if (lane == 0) {
+                atomicAdd(&sCnt[2], (uint32_t)__popcll(mPre));
+                if (mPreHi) atomicAdd(&sCnt[3], (uint32_t)__popcll(mPreHi));
+                if (mKeepHi) atomicAdd(&sCnt[1], (uint32_t)__popcll(mKeepHi));
+                if (mKeep) wbase = atomicAdd(&sCnt[0], (uint32_t)__popcll(mKeep));
+            }
+            wbase = __shfl(wbase, 0);
+            if (keep) {
+                const uint32_t rank = (uint32_t)__popcll(mKeep & ((1ull << lane) - 1ull));
+                sCand[wbase + rank] = pack_cand(x0 + ox, y0 + oy, s);
+            }
         }
     }
     __syncthreads();
 
-    // ---- NMS (strictly greater than all 8 neighbours, Fast_gpu.cu:300-310) + tile compaction ----
-    for (int e = tid; e < kFastTW * kFastTH; e += 256) {
-        const int oy = e / kFastTW;
-        const int ox = e - oy * kFastTW;
-        const int s = sScore[oy + 1][ox + 1];
-        bool keep = false;
-        if (s > 0) {
-            keep = s > sScore[oy][ox] && s > sScore[oy][ox + 1] && s > sScore[oy][ox + 2] &&
-                   s > sScore[oy + 1][ox] && s > sScore[oy + 1][ox + 2] && s > sScore[oy + 2][ox] &&
-                   s > sScore[oy + 2][ox + 1] && s > sScore[oy + 2][ox + 2];
-        }
-        const bool hi = s >= iniTh;
-        const unsigned long long mPre = __ballot(s > 0);
-        if (mPre == 0) continue;  // wave-uniform: nothing in these 64 pixels
-        const unsigned long long mPreHi = __ballot(s > 0 && hi);
-        const unsigned long long mKeep = __ballot(keep);
-        const unsigned long long mKeepHi = __ballot(keep && hi);
-        uint32_t wbase = 0;
-        if (lane == 0) {
-            atomicAdd(&sCnt[2], (uint32_t)__popcll(mPre));
-            if (mPreHi) atomicAdd(&sCnt[3], (uint32_t)__popcll(mPreHi));
-            if (mKeepHi) atomicAdd(&sCnt[1], (uint32_t)__popcll(mKeepHi));
-            if (mKeep) wbase = atomicAdd(&sCnt[0], (uint32_t)__popcll(mKeep));
-        }
-        wbase = __shfl(wbase, 0);
-        if (keep) {
-            const uint32_t rank = (uint32_t)__popcll(mKeep & ((1ull << lane) - 1ull));
-            sCand[wbase + rank] = pack_cand(x0 + ox, y0 + oy, s);
-        }
-    }
-    __syncthreads();
+    }  // MODE & 2
 
     uint32_t* cnt = counters + ((size_t)f * nL + l) * kCntWords;
     const uint32_t nTile = sCnt[0];
@@ -372,8 +433,22 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
 {
     dim3 block(256);
     dim3 grid(frames, totalTiles);
-    hipLaunchKernelGGL(fast_blur_kernel, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch,
-                       gray0Aligned4, ws, cand, counters);
+    static const int mode = [] {
+        const char* e = getenv("ORBFE_FAST_MODE");  // timing experiments only; results are wrong unless 3
+        return e ? atoi(e) & 15 : 3;
+    }();
+#define ORBFE_LAUNCH_FB(M)                                                                               \
+    hipLaunchKernelGGL(fast_blur_kernel<M>, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch, \
+                       gray0Aligned4, ws, cand, counters)
+    switch (mode) {
+    case 0: ORBFE_LAUNCH_FB(0); break;
+    case 1: ORBFE_LAUNCH_FB(1); break;
+    case 2: ORBFE_LAUNCH_FB(2); break;
+    case 6: ORBFE_LAUNCH_FB(6); break;    // FAST stage A only
+    case 10: ORBFE_LAUNCH_FB(10); break;  // FAST stages A + B only
+    default: ORBFE_LAUNCH_FB(3); break;
+    }
+#undef ORBFE_LAUNCH_FB
 }
 
 }  // namespace orbfe
