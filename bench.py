@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the MI355X ORB front-end (BASELINE.json metric).
 
-A "step" is one pass of the hot path (extract [+ SearchByProjection match]) over one batch of
-synthetic 752x480 frames that are already resident in HBM.  One process per GPU; for N > 1 launch
-with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env): every rank extracts its
-own shard of frames (weak scaling, no data-path collective) and the per-step results are gathered
-with one RCCL all_gather (the "trivial descriptor gather" of BASELINE.json config 4).
+A "step" is one pass of the hot path -- ORB extraction of a batch of synthetic 752x480 frames that
+are already resident in HBM, followed by SearchByProjection of 2000 map points per frame against
+the fresh keypoints (SURVEY.md section 8d, config C3 recipe).  One process per GPU; for N > 1 launch with
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env): every rank works on its own
+shard of frames (weak scaling, no data-path collective) and the per-step results are gathered with
+one RCCL all_gather (the "trivial descriptor gather" of BASELINE.json config 4).
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement), including
+Prints ONE JSON line on rank 0 (driver contract), including
   roofline     -- dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) timed on host cores.
 """
@@ -32,10 +33,14 @@ WORKLOADS = {
     "batched_1280x720": (2000, 100000, 1.2, 8, 20, 7, 1280, 720),
     "tumvi_1024x1024": (1500, 100000, 1.2, 12, 20, 7, 1024, 1024),
 }
+GRID = (64, 48)          # mFrameGridCols x mFrameGridRows (mono_inertial_node.cpp:187-188)
+MATCH_TH, MATCH_NN = 20.0, 0.85  # Tracking.cc:1108-1113 before IMU init
+N_MAP_POINTS = 2000
 
 
 def algorithmic_bytes_per_frame(ex, n_kp):
-    """B = 5P - px0 - px_{L-1} + 1317 N (compulsory traffic, materialised pyramids)."""
+    """Compulsory HBM traffic per frame with materialised pyramids (minus the P
+    bytes saved by reading each level once for both FAST and the Gaussian)."""
     px = ex.levelW.astype(np.int64) * ex.levelH.astype(np.int64)
     P = int(px.sum())
     per_stage = {
@@ -49,16 +54,47 @@ def algorithmic_bytes_per_frame(ex, n_kp):
     return per_stage, 4 * P - int(px[0]) - int(px[-1]) + 1317 * int(n_kp)
 
 
-def cpu_baseline(args_tuple, frames, budget_s):
+def make_map_points(kp, n, desc, M, rng, n_levels, mp_dtype):
+    """C3 recipe, vectorised: descriptor of a random keypoint with 0..20 bit flips, projection = that
+    keypoint +- 3 px, level = its octave."""
+    src = rng.integers(0, max(n, 1), M)
+    mps = np.zeros(M, mp_dtype)
+    mps["proj_x"] = kp["x"][src] + rng.uniform(-3, 3, M).astype(np.float32)
+    mps["proj_y"] = kp["y"][src] + rng.uniform(-3, 3, M).astype(np.float32)
+    mps["view_cos"] = 1.0
+    mps["track_depth"] = 1.0
+    mps["level"] = np.minimum(kp["octave"][src], n_levels - 1)
+    mps["in_view"] = 1
+    mps["observations"] = rng.integers(0, 4, M)
+    d = desc[src].copy()
+    nflip = rng.integers(0, 21, M)
+    for j in range(20):
+        act = np.nonzero(j < nflip)[0]
+        pos = rng.integers(0, 256, len(act))
+        np.bitwise_xor.at(d, (act, pos >> 3), (1 << (pos & 7)).astype(np.uint8))
+    return mps, d
+
+
+def cpu_baseline(args_tuple, frames, budget_s, with_match, mp_dtype):
+    """Single-thread CPU oracle on a bounded sample of the same stream (extract [+ match])."""
     import oracle_py as O
     ref = O.Extractor(*args_tuple)
+    W, H = args_tuple[6], args_tuple[7]
+    rng = np.random.default_rng(7)
     ref.extract(frames[0])  # warm
     t0 = time.perf_counter()
     n = 0
-    while n < len(frames) and (time.perf_counter() - t0 < budget_s or n < 3):
-        ref.extract(frames[n])
+    t_gen = 0.0
+    while n < len(frames) and (time.perf_counter() - t0 - t_gen < budget_s or n < 3):
+        kp, desc, _ = ref.extract(frames[n])
+        if with_match and len(kp):
+            tg = time.perf_counter()
+            mps, mpd = make_map_points(kp, len(kp), desc, N_MAP_POINTS, rng, ref.nLevels, mp_dtype)
+            fv = O.make_frame_view(kp, desc, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors)
+            t_gen += time.perf_counter() - tg  # input synthesis is not part of the measured path
+            O.search_by_projection(fv, mps.view(O.MP_DTYPE), mpd, None, MATCH_TH, MATCH_NN)
         n += 1
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 - t_gen
     return n / dt, n
 
 
@@ -72,6 +108,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="extract only")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,6 +120,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # everything (our kernels, torch copies, the RCCL gather) is ordered on ONE explicit stream; the
+    # default stream's handle is 0, which the C ABI reads as "use the handle's own stream"
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -96,7 +136,9 @@ def main():
     cfg = WORKLOADS[a.workload]
     W, H = cfg[6], cfg[7]
     B = a.batch
+    M = 0 if a.no_match else N_MAP_POINTS
     ex = orbfe.ORBextractor(*cfg, device=local_rank, max_batch=B)
+    matcher = orbfe.ORBmatcher(ex)
     cap = ex.cap
 
     # ---- synthetic stream, resident in HBM before the timed region ----
@@ -106,19 +148,51 @@ def main():
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
     d_per = torch.zeros((B, ex.nlevels), dtype=torch.int32, device=dev)
+    d_match = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+    d_nmatch = torch.zeros(B, dtype=torch.int32, device=dev)
     gather = world > 1 and not a.no_gather
     if gather:
-        pack = torch.zeros((B, cap, 56), dtype=torch.uint8, device=dev)
-        g_out = torch.zeros((world, B, cap, 56), dtype=torch.uint8, device=dev)
+        pack = torch.zeros((B, cap, 60), dtype=torch.uint8, device=dev)  # kp 24 + desc 32 + match 4
+        g_out = torch.zeros((world, B, cap, 60), dtype=torch.uint8, device=dev)
         g_n = torch.zeros((world, B), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
-    def step():
+    def extract():
         ex.extract_batch_device(d_gray.data_ptr(), W * H, W, B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(),
                                 d_per.data_ptr(), stream.cuda_stream)
+
+    # ---- map points (C3 recipe) from one untimed extraction; resident in HBM as well ----
+    extract()
+    torch.cuda.synchronize(dev)
+    if M:
+        kp_h = d_kp.cpu().numpy().reshape(B, cap * 24).view(orbfe.KP_DTYPE).reshape(B, cap)
+        desc_h = d_desc.cpu().numpy()
+        n_h = d_n.cpu().numpy()
+        rng = np.random.default_rng(1234 + rank)
+        mps_all = np.zeros((B, M), orbfe.MP_DTYPE)
+        mpd_all = np.zeros((B, M, 32), np.uint8)
+        for b in range(B):
+            mps_all[b], mpd_all[b] = make_map_points(kp_h[b], int(n_h[b]), desc_h[b], M, rng, ex.nlevels, orbfe.MP_DTYPE)
+        d_mps = torch.from_numpy(mps_all.view(np.uint8).reshape(-1)).to(dev)
+        d_mpd = torch.from_numpy(mpd_all.reshape(-1)).to(dev)
+    ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+
+    def step(i=None):
+        extract()
+        if M:
+            if i is not None:
+                ev_m0[i].record(stream)
+            matcher.SearchByProjection_batch_device(B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, GRID[0],
+                                                    GRID[1], 0.0, 0.0, float(W), float(H), M, d_mps.data_ptr(),
+                                                    d_mpd.data_ptr(), None, MATCH_TH, MATCH_NN, d_match.data_ptr(),
+                                                    d_nmatch.data_ptr(), stream=stream.cuda_stream)
+            if i is not None:
+                ev_m1[i].record(stream)
         if gather:
             pack[:, :, :24] = d_kp
-            pack[:, :, 24:] = d_desc
+            pack[:, :, 24:56] = d_desc
+            pack[:, :, 56:] = d_match.view(torch.uint8).reshape(B, cap, 4)
             dist.all_gather_into_tensor(g_out, pack)
             dist.all_gather_into_tensor(g_n, d_n)
 
@@ -133,8 +207,8 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for i in range(a.steps):
+        step(i)
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
@@ -148,12 +222,17 @@ def main():
     n_kp_mean = float(d_n.float().mean().item())
     if rank == 0:
         per_stage_bytes, b_frame = algorithmic_bytes_per_frame(ex, n_kp_mean)
-        kernel_stages = [s for s in stage_ms if s != "total"]
-        dom = max(kernel_stages, key=lambda s: stage_ms[s])
-        dom_ms = stage_ms[dom] / max(1, ncalls)
+        stage_avg = {k: v / max(1, ncalls) for k, v in stage_ms.items()}
+        if M:
+            stage_avg["match_projection"] = sum(e0.elapsed_time(e1) for e0, e1 in zip(ev_m0, ev_m1)) / a.steps
+        kernel_stages = [s for s in per_stage_bytes]
+        dom = max(kernel_stages, key=lambda s: stage_avg[s])
+        dom_ms = stage_avg[dom]
         dom_bytes = per_stage_bytes[dom] * B
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        total_ms = stage_ms["total"] / max(1, ncalls)
+        total_ms = stage_avg["total"]
+        what = "extract-only" if not M else "extract + SearchByProjection(%d map points/frame, grid %dx%d, th=%g, nnRatio=%g)" % (
+            M, GRID[0], GRID[1], MATCH_TH, MATCH_NN)
         out = {
             "metric": "frames/sec ORB extract+match, 752x480 8-level 1000-feat; bit-exact kp/desc",
             "value": world * B * a.steps / dt,
@@ -167,23 +246,23 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s extract-only, %d frames/step/GPU resident in HBM, nFeatures=%d levels=%d "
-                                   "scale=%.1f FAST %d/%d nFast=%d" % (a.workload, B, cfg[0], cfg[3], cfg[2], cfg[4],
+            "config": {"workload": "%s synthetic stream, %s, %d frames/step/GPU resident in HBM, nFeatures=%d levels=%d "
+                                   "scale=%.1f FAST %d/%d nFast=%d" % (a.workload, what, B, cfg[0], cfg[3], cfg[2], cfg[4],
                                                                          cfg[5], cfg[1]),
                        "frames_per_step": B * world, "mean_keypoints_per_frame": n_kp_mean,
-                       "gather": "rccl all_gather of kp+desc per step" if gather else "none"},
+                       "mean_matches_per_frame": float(d_nmatch.float().mean().item()) if M else None,
+                       "gather": "rccl all_gather of kp+desc+match per step" if gather else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
-                         "pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
-                         "stage_ms_per_step": {k: v / max(1, ncalls) for k, v in stage_ms.items()}},
+                         "extract_pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
+                         "stage_ms_per_step": stage_avg},
         }
         if not a.no_cpu_baseline:
-            nsample = 64
-            fps, n = cpu_baseline(cfg, frames[:nsample], a.cpu_seconds)
+            fps, n = cpu_baseline(cfg, frames[:64], a.cpu_seconds, bool(M), orbfe.MP_DTYPE)
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frames of the same stream through the single-thread C oracle "
-                                             "(extract only), host %s, nproc=%d" % (n, os.uname().machine, os.cpu_count())}
+                                   "sample": "%d frames of the same stream through the single-thread C oracle (%s), "
+                                             "host nproc=%d" % (n, what.split("(")[0].strip(), os.cpu_count())}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,208 @@
+// kernels_match_bow.hip -- ORBmatcher::SearchByBoW on gfx950 (src/ORBmatcher.cc:133-327 incl.
+// ComputeThreeMaxima :1328-1370).  A frame feature belongs to exactly one vocabulary node, so the
+// greedy "already matched" skips (:188) never cross nodes: one wave walks the key-frame features of
+// a node sequentially and scans the node's frame features in parallel (top-2 under the total order
+// (distance, position in the node's list)); a single block then applies the rotation histogram.
+#include <algorithm>
+#include <cstring>
+
+#include "match_common.h"
+
+#pragma clang fp contract(off)
+
+namespace orbfe {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// SearchByBoW
+// ------------------------------------------------------------------------------------------------
+struct BowArgs {
+    int G;
+    const int *kfOff, *kfIdx, *fOff, *fIdx;
+    const uint8_t *kfDesc, *fDesc, *kfHasMP;
+    const float *kfAngle, *fAngle;
+    int nF;
+    float nnRatio;
+    int checkOrientation;
+    int* matchOut;   // [nF], -1 initialised
+    int* binOf;      // [nF]
+    int* nMatches;   // [1]
+};
+
+__global__ __launch_bounds__(256) void bow_match_kernel(BowArgs A)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= A.G) return;
+    const int k0 = A.kfOff[g], k1e = A.kfOff[g + 1];
+    const int f0 = A.fOff[g], f1 = A.fOff[g + 1];
+    const float factor = 1.0f / ORBFE_HISTO_LENGTH;
+    for (int iKF = k0; iKF < k1e; iKF++) {  // sequential: later KF features skip matched frame features (:188)
+        const int realIdxKF = A.kfIdx[iKF];
+        if (!A.kfHasMP[realIdxKF]) continue;
+        unsigned long long d4[4];
+        {
+            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.kfDesc + (size_t)realIdxKF * 32);
+            d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
+        }
+        unsigned long long k1 = kKeyNone, k2 = kKeyNone;
+        for (int iF = f0 + lane; iF < f1; iF += 64) {
+            const int realIdxF = A.fIdx[iF];
+            if (A.matchOut[realIdxF] >= 0) continue;
+            const int dist = hamming256(reinterpret_cast<const uint2*>(A.fDesc + (size_t)realIdxF * 32), d4);
+            if (dist >= 256) continue;
+            const unsigned long long key = ((unsigned long long)dist << 32) | (unsigned)(iF - f0);
+            if (key < k1) { k2 = k1; k1 = key; }
+            else if (key < k2) k2 = key;
+        }
+        wave_top2(k1, k2);
+        if (k1 == kKeyNone) continue;
+        const int bestDist1 = (int)(k1 >> 32);
+        const int bestDist2 = k2 == kKeyNone ? 256 : (int)(k2 >> 32);
+        if (bestDist1 <= ORBFE_TH_LOW && (float)bestDist1 < A.nnRatio * (float)bestDist2) {  // :237-239
+            const int bestIdxF = A.fIdx[f0 + (int)(k1 & 0xffffffffu)];
+            if (lane == 0) {
+                A.matchOut[bestIdxF] = realIdxKF;
+                if (A.checkOrientation) {
+                    float rot = A.kfAngle[realIdxKF] - A.fAngle[bestIdxF];
+                    if (rot < 0.0) rot = rot + 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+                    A.binOf[bestIdxF] = bin;
+                }
+            }
+            __threadfence_block();  // later iterations of this wave read matchOut
+        }
+    }
+}
+
+// rotation-histogram filter (:304-322) + count; single block
+__global__ __launch_bounds__(256) void bow_finalize_kernel(BowArgs A)
+{
+    __shared__ int hist[ORBFE_HISTO_LENGTH];
+    __shared__ int sInd[3];
+    __shared__ int sCount;
+    const int tid = threadIdx.x;
+    if (tid < ORBFE_HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    int local = 0;
+    for (int j = tid; j < A.nF; j += blockDim.x)
+        if (A.matchOut[j] >= 0) {
+            local++;
+            if (A.checkOrientation) atomicAdd(&hist[A.binOf[j]], 1);
+        }
+    __syncthreads();
+    if (tid == 0) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        if (A.checkOrientation) {  // ComputeThreeMaxima :1328-1370
+            int max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < ORBFE_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        }
+        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+    }
+    __syncthreads();
+    if (A.checkOrientation) {
+        for (int j = tid; j < A.nF; j += blockDim.x)
+            if (A.matchOut[j] >= 0) {
+                const int b = A.binOf[j];
+                if (b != sInd[0] && b != sInd[1] && b != sInd[2]) {
+                    A.matchOut[j] = -1;
+                    local--;
+                }
+            }
+    }
+    if (local) atomicAdd(&sCount, local);
+    __syncthreads();
+    if (tid == 0) *A.nMatches = sCount;
+}
+
+}  // namespace
+
+int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const int* kfIdx, const int* fOff,
+                  const int* fIdx, int nKF, const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfHasMP, int nF,
+                  const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation, int* matchOut,
+                  int* nMatches, std::string& err)
+{
+    for (int i = 0; i < nF; i++) matchOut[i] = -1;
+    *nMatches = 0;
+    if (G == 0 || nF == 0 || nKF == 0) return ORBFE_OK;
+    const int nKfIdx = kfOff[G], nFIdx = fOff[G];
+    for (int g = 0; g < G; g++)
+        if (kfOff[g + 1] < kfOff[g] || fOff[g + 1] < fOff[g]) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < nKfIdx; i++)
+        if (kfIdx[i] < 0 || kfIdx[i] >= nKF) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < nFIdx; i++)
+        if (fIdx[i] < 0 || fIdx[i] >= nF) return ORBFE_ERR_INVALID_ARG;
+
+    Carver in;
+    const size_t oKfOff = in.take((size_t)(G + 1) * sizeof(int));
+    const size_t oFOff = in.take((size_t)(G + 1) * sizeof(int));
+    const size_t oKfIdx = in.take((size_t)std::max(nKfIdx, 1) * sizeof(int));
+    const size_t oFIdx = in.take((size_t)std::max(nFIdx, 1) * sizeof(int));
+    const size_t oKfDesc = in.take((size_t)nKF * 32);
+    const size_t oFDesc = in.take((size_t)nF * 32);
+    const size_t oKfHas = in.take((size_t)nKF);
+    const size_t oKfAng = in.take((size_t)nKF * sizeof(float));
+    const size_t oFAng = in.take((size_t)nF * sizeof(float));
+    const size_t inBytes = in.off;
+    Carver sc = in;
+    const size_t oMatch = sc.take((size_t)nF * sizeof(int));
+    const size_t oBin = sc.take((size_t)nF * sizeof(int));
+    const size_t oNM = sc.take(sizeof(int));
+    int rc = ensure(m, sc.off, inBytes + (size_t)nF * sizeof(int) + 256, err);
+    if (rc != ORBFE_OK) return rc;
+    uint8_t* hp = static_cast<uint8_t*>(m.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(m.d);
+    memcpy(hp + oKfOff, kfOff, (size_t)(G + 1) * sizeof(int));
+    memcpy(hp + oFOff, fOff, (size_t)(G + 1) * sizeof(int));
+    memcpy(hp + oKfIdx, kfIdx, (size_t)nKfIdx * sizeof(int));
+    memcpy(hp + oFIdx, fIdx, (size_t)nFIdx * sizeof(int));
+    memcpy(hp + oKfDesc, kfDesc, (size_t)nKF * 32);
+    memcpy(hp + oFDesc, fDesc, (size_t)nF * 32);
+    memcpy(hp + oKfHas, kfHasMP, (size_t)nKF);
+    if (kfAngle) memcpy(hp + oKfAng, kfAngle, (size_t)nKF * sizeof(float));
+    if (fAngle) memcpy(hp + oFAng, fAngle, (size_t)nF * sizeof(float));
+    MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
+
+    BowArgs A{};
+    A.G = G;
+    A.kfOff = reinterpret_cast<const int*>(dp + oKfOff);
+    A.fOff = reinterpret_cast<const int*>(dp + oFOff);
+    A.kfIdx = reinterpret_cast<const int*>(dp + oKfIdx);
+    A.fIdx = reinterpret_cast<const int*>(dp + oFIdx);
+    A.kfDesc = dp + oKfDesc;
+    A.fDesc = dp + oFDesc;
+    A.kfHasMP = dp + oKfHas;
+    A.kfAngle = reinterpret_cast<const float*>(dp + oKfAng);
+    A.fAngle = reinterpret_cast<const float*>(dp + oFAng);
+    A.nF = nF;
+    A.nnRatio = nnRatio;
+    A.checkOrientation = checkOrientation;
+    A.matchOut = reinterpret_cast<int*>(dp + oMatch);
+    A.binOf = reinterpret_cast<int*>(dp + oBin);
+    A.nMatches = reinterpret_cast<int*>(dp + oNM);
+    const dim3 blk(256);
+    hipLaunchKernelGGL(fill_kernel, dim3((nF + 255) / 256), blk, 0, s, A.matchOut, -1, (size_t)nF);
+    hipLaunchKernelGGL(bow_match_kernel, dim3((G + 3) / 4), blk, 0, s, A);
+    hipLaunchKernelGGL(bow_finalize_kernel, dim3(1), blk, 0, s, A);
+    MCHK(hipGetLastError());
+    int* hMatch = reinterpret_cast<int*>(hp + inBytes);
+    int* hNM = hMatch + nF;
+    MCHK(hipMemcpyAsync(hMatch, A.matchOut, (size_t)nF * sizeof(int), hipMemcpyDeviceToHost, s));
+    MCHK(hipMemcpyAsync(hNM, A.nMatches, sizeof(int), hipMemcpyDeviceToHost, s));
+    MCHK(hipStreamSynchronize(s));
+    memcpy(matchOut, hMatch, (size_t)nF * sizeof(int));
+    *nMatches = *hNM;
+    return ORBFE_OK;
+}
+
+}  // namespace orbfe
