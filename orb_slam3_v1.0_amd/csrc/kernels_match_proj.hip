@@ -26,6 +26,8 @@
 //   keypoints + descriptors staged in LDS) -> ONE persistent block per frame resolves the claims
 //   (claim table in LDS) and writes the final matches.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "match_common.h"
@@ -38,7 +40,6 @@ namespace {
 
 constexpr int kClaimFree = 0x7fffffff;
 constexpr int kResolveThreads = 1024;
-constexpr int kLdsClaims = 8192;  // keypoints per frame whose claim table fits the LDS budget (32 KB)
 constexpr int kTopK = 16;         // stored candidates per map point
 constexpr int kCandChunk = 1024;  // keypoints staged in LDS per pass (48 B each)
 
@@ -66,6 +67,7 @@ struct ProjArgs {
     unsigned long long* topk;     // [B][kTopK][M] sorted smallest keys (entry-major: coalesced per sweep)
     int* claimG;                  // [B][kpStride] fallback claim table (n > kLdsClaims)
     int* perm;                    // [B][M] map points ordered by pyramid level (work assignment of the top-K pass)
+    int* dbg;                     // [B][4] diagnostics: sweeps, cooperative rescans, chunks, -
     int* matchOut;                // [B][kpStride]
     int* nMatches;                // [B]
 };
@@ -145,36 +147,46 @@ __global__ void proj_prep_kernel(ProjArgs A)
     A.matchOut[(size_t)f * A.kpStride + i] = -1;
 }
 
-// Counting sort of a frame's map points by pyramid level (bucket 32 = invalid): only the WORK
-// ASSIGNMENT of the top-K pass uses this order, so that the 64 lanes of a wave search the same
-// levels and whole-wave early exits skip the keypoints of all other levels.  Results stay indexed
-// by the original map point order.
+// Counting sort of a frame's map points by (pyramid level, 8 x 6 spatial tile); the last bucket
+// holds the invalid ones.  Only the WORK ASSIGNMENT of the top-K pass uses this order: the 64 lanes
+// of a wave then search the same levels in overlapping windows, so a keypoint is relevant either
+// for most lanes or for none and the whole wave skips it.  Results stay indexed by the original
+// map point order.
+constexpr int kTilesX = 8, kTilesY = 6;
+constexpr int kSortBuckets = 32 * kTilesX * kTilesY + 1;
+
+__device__ __forceinline__ int sort_bucket(const ProjArgs& A, const orbfe_map_point& mp)
+{
+    const bool valid = mp.in_view && !(A.farPoints && mp.track_depth > A.thFar) && !mp.bad;
+    if (!valid) return kSortBuckets - 1;
+    const int lvl = min(max(mp.level, 0), 31);
+    const int cx = (int)((mp.proj_x - A.g.minX) * A.g.invW), cy = (int)((mp.proj_y - A.g.minY) * A.g.invH);
+    const int tx = min(max(cx * kTilesX / A.g.cols, 0), kTilesX - 1);
+    const int ty = min(max(cy * kTilesY / A.g.rows, 0), kTilesY - 1);
+    return (lvl * kTilesY + ty) * kTilesX + tx;
+}
+
 __global__ __launch_bounds__(1024) void proj_sort_kernel(ProjArgs A)
 {
-    __shared__ int sHist[33], sBase[33];
+    __shared__ int sHist[kSortBuckets];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
-    if (tid < 33) sHist[tid] = 0;
+    for (int b = tid; b < kSortBuckets; b += 1024) sHist[b] = 0;
     __syncthreads();
     const orbfe_map_point* mps = A.mps + (size_t)f * A.M;
-    for (int i = tid; i < A.M; i += 1024) {
-        const orbfe_map_point& mp = mps[i];
-        const bool valid = mp.in_view && !(A.farPoints && mp.track_depth > A.thFar) && !mp.bad;
-        atomicAdd(&sHist[valid ? min(max(mp.level, 0), 31) : 32], 1);
-    }
+    for (int i = tid; i < A.M; i += 1024) atomicAdd(&sHist[sort_bucket(A, mps[i])], 1);
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {  // exclusive prefix in place (1537 entries, once per frame)
         int acc = 0;
-        for (int b = 0; b < 33; b++) {
-            sBase[b] = acc;
-            acc += sHist[b];
+        for (int b = 0; b < kSortBuckets; b++) {
+            const int c = sHist[b];
+            sHist[b] = acc;
+            acc += c;
         }
     }
     __syncthreads();
     for (int i = tid; i < A.M; i += 1024) {
-        const orbfe_map_point& mp = mps[i];
-        const bool valid = mp.in_view && !(A.farPoints && mp.track_depth > A.thFar) && !mp.bad;
-        const int pos = atomicAdd(&sBase[valid ? min(max(mp.level, 0), 31) : 32], 1);
+        const int pos = atomicAdd(&sHist[sort_bucket(A, mps[i])], 1);
         A.perm[(size_t)f * A.M + pos] = i;
     }
 }
@@ -184,10 +196,7 @@ __global__ __launch_bounds__(1024) void proj_sort_kernel(ProjArgs A)
 // Every lane looks at the same keypoint at the same time -> LDS broadcast reads.
 __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
 {
-    __shared__ int sCell[kCandChunk];
-    __shared__ float sX[kCandChunk];
-    __shared__ float sY[kCandChunk];
-    __shared__ int sOct[kCandChunk];
+    __shared__ int4 sKp[kCandChunk];  // {cell, octave, x bits, y bits}: one ds_read_b128 per keypoint
     __shared__ unsigned long long sDesc[kCandChunk][4];
     const int f = blockIdx.y;
     const int slotIdx = blockIdx.x * 256 + threadIdx.x;
@@ -215,17 +224,18 @@ __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
         __syncthreads();
         for (int j = threadIdx.x; j < m; j += 256) {
             const orbfe_keypoint k = kp[base + j];
-            sCell[j] = cellXY[base + j];
-            sX[j] = k.x;
-            sY[j] = k.y;
-            sOct[j] = k.octave;
+            sKp[j] = make_int4(cellXY[base + j], k.octave, __float_as_int(k.x), __float_as_int(k.y));
         }
         for (int j = threadIdx.x; j < m * 4; j += 256) sDesc[0][j] = desc[(size_t)base * 4 + j];
         __syncthreads();
         if (w.valid) {
+            const bool checkLevels = (w.minLevel > 0) || (w.maxLevel >= 0);  // src/Frame.cc:437
             for (int j = 0; j < m; j++) {
-                const int cell = sCell[j];
-                if (!in_window(w, cell, sX[j], sY[j], sOct[j])) continue;
+                const int4 kq = sKp[j];  // broadcast read
+                const int cell = kq.x, oct = kq.y;
+                // level filter first: waves are level-coherent, so most keypoints fail for all 64 lanes
+                if (checkLevels && (oct < w.minLevel || (w.maxLevel >= 0 && oct > w.maxLevel))) continue;
+                if (!in_window(w, cell, __int_as_float(kq.z), __int_as_float(kq.w), oct)) continue;
                 const int dist = __popcll(sDesc[j][0] ^ d4[0]) + __popcll(sDesc[j][1] ^ d4[1]) +
                                  __popcll(sDesc[j][2] ^ d4[2]) + __popcll(sDesc[j][3] ^ d4[3]);
                 if (dist >= 256) continue;  // can enter neither slot (the reference's bests start at 256)
@@ -249,10 +259,24 @@ __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
     }
 }
 
-// exact fallback for a map point whose stored top-K ran dry: one WAVE scans all keypoints of the
-// frame (lane-strided, coalesced) and reduces the two smallest free keys; all lanes get the result
-__device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, int i, const int* claim, int lane,
-                                                    unsigned long long& k1, unsigned long long& k2)
+// One persistent block per frame, one THREAD per map point, chunks of 1024 map points in index order.
+// The frame's keypoints (cell, octave, x, y) and descriptors are staged in LDS once (frames up to
+// kResN keypoints), so sweeps and the exact rescans of starved map points never touch global memory.
+constexpr int kResN = 2048;
+
+struct ResolveLds {
+    int claim[kResN];
+    int4 kp[kResN];                       // {cell, octave, x bits, y bits}
+    unsigned long long desc[kResN][4];
+};
+
+// exact rescan for a map point whose stored top-K ran dry: one WAVE scans all keypoints of the
+// frame (lane-strided) and reduces the two smallest free keys; all lanes get the result.
+// The claim test goes first: a starved map point sits in a region where nearly everything is taken.
+template <bool LDS>
+__device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, int i, const int* claim,
+                                                    const ResolveLds* S, int lane, unsigned long long& k1,
+                                                    unsigned long long& k2)
 {
     const MpWindow w = mp_window(A, A.mps[(size_t)f * A.M + i]);
     k1 = kKeyNone;
@@ -266,12 +290,23 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
         const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * A.M + i) * 32);
         d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
         for (int idx = lane; idx < n; idx += 64) {
-            const int cell = cellXY[idx];
-            if (cell < 0) continue;
-            const orbfe_keypoint k = kp[idx];
-            if (!in_window(w, cell, k.x, k.y, k.octave)) continue;
             if (claim[idx] < i) continue;
-            const int dist = hamming256(reinterpret_cast<const uint2*>(desc + (size_t)idx * 32), d4);
+            int cell, oct, dist;
+            float kx, ky;
+            if (LDS) {
+                const int4 q = S->kp[idx];
+                cell = q.x; oct = q.y; kx = __int_as_float(q.z); ky = __int_as_float(q.w);
+            } else {
+                cell = cellXY[idx];
+                const orbfe_keypoint k = kp[idx];
+                oct = k.octave; kx = k.x; ky = k.y;
+            }
+            if (!in_window(w, cell, kx, ky, oct)) continue;
+            if (LDS)
+                dist = __popcll(S->desc[idx][0] ^ d4[0]) + __popcll(S->desc[idx][1] ^ d4[1]) +
+                       __popcll(S->desc[idx][2] ^ d4[2]) + __popcll(S->desc[idx][3] ^ d4[3]);
+            else
+                dist = hamming256(reinterpret_cast<const uint2*>(desc + (size_t)idx * 32), d4);
             if (dist >= 256) continue;
             const unsigned long long key = make_key(dist, cell, idx);
             if (key < k1) { k2 = k1; k1 = key; }
@@ -281,10 +316,10 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
     wave_top2(k1, k2);
 }
 
-// One persistent block per frame, one THREAD per map point, chunks of 1024 map points in index order.
+template <bool LDS>
 __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs A)
 {
-    __shared__ int sClaim[kLdsClaims];
+    __shared__ ResolveLds S;
     __shared__ int sChanged;
     __shared__ int sCount;
     __shared__ int sFbCount;                             // starved map points of the current sweep
@@ -294,7 +329,7 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
     const int tid = threadIdx.x;
     const int n = A.nKp[f];
     const int M = A.M;
-    int* claim = n <= kLdsClaims ? sClaim : A.claimG + (size_t)f * A.kpStride;
+    int* claim = LDS ? S.claim : A.claimG + (size_t)f * A.kpStride;
     const orbfe_map_point* mps = A.mps + (size_t)f * M;
     const orbfe_keypoint* kp = A.kp + (size_t)f * A.kpStride;
     const int* initObs = A.initObs ? A.initObs + (size_t)f * A.kpStride : nullptr;
@@ -302,6 +337,15 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
     // claim[idx] = -1 if the slot holds a map point with observations on entry (:77-79); later the
     // smallest accepted map point (with observations) whose best match is idx
     for (int i = tid; i < n; i += kResolveThreads) claim[i] = (initObs && initObs[i] > 0) ? -1 : kClaimFree;
+    if (LDS) {
+        const int* cellXY = A.cellXY + (size_t)f * A.kpStride;
+        const unsigned long long* desc = reinterpret_cast<const unsigned long long*>(A.desc + (size_t)f * A.kpStride * 32);
+        for (int j = tid; j < n; j += kResolveThreads) {
+            const orbfe_keypoint k = kp[j];
+            S.kp[j] = make_int4(cellXY[j], k.octave, __float_as_int(k.x), __float_as_int(k.y));
+        }
+        for (int j = tid; j < n * 4; j += kResolveThreads) S.desc[0][j] = desc[j];
+    }
     if (tid == 0) sCount = 0;
     int nAccepted = 0;
 
@@ -359,6 +403,7 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
                     if (!decided) {  // exact rescan, done cooperatively below
                         slot = atomicAdd(&sFbCount, 1);
                         sFbMp[slot] = i;
+                        atomicAdd(&A.dbg[f * 4 + 1], 1);
                     }
                 }
             }
@@ -367,25 +412,24 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
                 const int nFb = sFbCount;
                 for (int q = tid >> 6; q < nFb; q += kResolveThreads / 64) {  // one wave per starved map point
                     unsigned long long a1, a2;
-                    full_scan_top2_wave(A, f, sFbMp[q], claim, tid & 63, a1, a2);
+                    full_scan_top2_wave<LDS>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
                     if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
                 }
             }
             __syncthreads();
             if (slot >= 0) { k1 = sFbK1[slot]; k2 = sFbK2[slot]; }
-            if (c > 0) {
-                if (k1 != kKeyNone) {
-                    const int bestDist = (int)(k1 >> 52), bestIdx = (int)(k1 & 0xFFFFF);
-                    const int bestLevel = kp[bestIdx].octave;
-                    int bestDist2 = 256, bestLevel2 = -1;
-                    if (k2 != kKeyNone) {
-                        bestDist2 = (int)(k2 >> 52);
-                        bestLevel2 = kp[(int)(k2 & 0xFFFFF)].octave;
-                    }
-                    if (bestDist <= ORBFE_TH_HIGH) {  // :108-117
-                        const bool reject = bestLevel == bestLevel2 && (float)bestDist > A.nnRatio * (float)bestDist2;
-                        if (!reject) result = bestIdx;
-                    }
+            if (k1 != kKeyNone) {
+                const int bestDist = (int)(k1 >> 52), bestIdx = (int)(k1 & 0xFFFFF);
+                const int bestLevel = LDS ? S.kp[bestIdx].y : kp[bestIdx].octave;
+                int bestDist2 = 256, bestLevel2 = -1;
+                if (k2 != kKeyNone) {
+                    bestDist2 = (int)(k2 >> 52);
+                    const int i2 = (int)(k2 & 0xFFFFF);
+                    bestLevel2 = LDS ? S.kp[i2].y : kp[i2].octave;
+                }
+                if (bestDist <= ORBFE_TH_HIGH) {  // :108-117
+                    const bool reject = bestLevel == bestLevel2 && (float)bestDist > A.nnRatio * (float)bestDist2;
+                    if (!reject) result = bestIdx;
                 }
             }
             if (result != res) {
@@ -393,6 +437,7 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
                 sChanged = 1;
             }
             __syncthreads();
+            if (tid == 0) atomicAdd(&A.dbg[f * 4 + 0], 1);
             if (!sChanged) break;
         }
         // F->mvpMapPoints[bestIdx] = pMP in map-point order: the last writer wins; nmatches counts accepts
@@ -415,6 +460,7 @@ int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::st
     const size_t oTopk = sc.take((size_t)B * kTopK * std::max(M, 1) * sizeof(unsigned long long));
     const size_t oClaim = sc.take((size_t)B * A.kpStride * sizeof(int));
     const size_t oPerm = sc.take((size_t)B * std::max(M, 1) * sizeof(int));
+    const size_t oDbg = sc.take((size_t)B * 4 * sizeof(int));
     int rc = ensure(m, sc.off, hostNeed + 256, err);
     if (rc != ORBFE_OK) return rc;
     uint8_t* dp = static_cast<uint8_t*>(m.d);
@@ -423,6 +469,7 @@ int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::st
     A.topk = reinterpret_cast<unsigned long long*>(dp + oTopk);
     A.claimG = reinterpret_cast<int*>(dp + oClaim);
     A.perm = reinterpret_cast<int*>(dp + oPerm);
+    A.dbg = reinterpret_cast<int*>(dp + oDbg);
     return ORBFE_OK;
 }
 
@@ -434,9 +481,13 @@ int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
         MCHK(hipMemsetAsync(A.nMatches, 0, (size_t)A.B * sizeof(int), s));
         return ORBFE_OK;
     }
+    MCHK(hipMemsetAsync(A.dbg, 0, (size_t)A.B * 4 * sizeof(int), s));
     hipLaunchKernelGGL(proj_sort_kernel, dim3(A.B), dim3(1024), 0, s, A);
     hipLaunchKernelGGL(proj_topk_kernel, dim3((A.M + 255) / 256, A.B), blk, 0, s, A);
-    hipLaunchKernelGGL(proj_resolve_kernel, dim3(A.B), dim3(kResolveThreads), 0, s, A);
+    if (A.kpStride <= kResN)  // nKp[f] <= kpStride: the whole frame fits the LDS image
+        hipLaunchKernelGGL(proj_resolve_kernel<true>, dim3(A.B), dim3(kResolveThreads), 0, s, A);
+    else
+        hipLaunchKernelGGL(proj_resolve_kernel<false>, dim3(A.B), dim3(kResolveThreads), 0, s, A);
     MCHK(hipGetLastError());
     return ORBFE_OK;
 }
@@ -510,6 +561,11 @@ int match_projection_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view*
     MCHK(hipMemcpyAsync(hMatch, A.matchOut, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
     MCHK(hipMemcpyAsync(hNM, A.nMatches, sizeof(int), hipMemcpyDeviceToHost, s));
     MCHK(hipStreamSynchronize(s));
+    if (getenv("ORBFE_DEBUG_MATCH")) {  // diagnostics only
+        int dbg[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(dbg, A.dbg, sizeof dbg, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[orbfe] match_projection: n=%d M=%d sweeps=%d cooperative_rescans=%d\n", n, M, dbg[0], dbg[1]);
+    }
     memcpy(matchOut, hMatch, (size_t)n * sizeof(int));
     *nMatches = *hNM;
     return ORBFE_OK;
