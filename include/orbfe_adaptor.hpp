@@ -1,0 +1,237 @@
+// orbfe_adaptor.hpp -- header-only C++17 adaptor that keeps the reference's public signatures on
+// top of the C ABI (include/orbfe.h), so src/Frame.cc / src/Tracking.cc call the MI355X front-end
+// unchanged.
+//
+//   ORB_SLAM3::ORBextractor   mirrors include/ORBextractor.h:52-130 (ctor :55-56, extractFeatures
+//                             :62, the six getters :64-92)
+//   ORB_SLAM3::ORBmatcher     mirrors include/ORBmatcher.h:36-84 for the functions on the hot path
+//                             (DescriptorDistance :41, SearchByProjection :45, SearchByBoW :55)
+//
+// Without OpenCV (this repository's build) the image / descriptor containers are plain views and
+// std::vector; define ORBFE_WITH_OPENCV in a tree that has OpenCV-CUDA to get the exact reference
+// types (cv::cuda::HostMem in, HostMem N x 32 out).  The matcher wrappers are templates over the
+// Frame / KeyFrame / MapPoint types: they only name the members the reference functions read
+// (mvKeysUn, mDescriptors, mvpMapPoints, mbTrackInView, ...), so they instantiate against the real
+// classes in the reference tree and against light mock types in tests/cpp/test_adaptor.cpp.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "orbfe.h"
+
+#ifdef ORBFE_WITH_OPENCV
+#include <opencv2/core/cuda.hpp>
+#include <KeyPoint.h>  // the reference's ORB_SLAM3::KeyPoint
+#endif
+
+namespace ORB_SLAM3 {
+
+#ifndef ORBFE_WITH_OPENCV
+// include/KeyPoint.h:7-12 without cv::Point2f (same 24-byte layout: pt.x, pt.y, response, size, octave, angle)
+struct KeyPoint {
+    struct { float x, y; } pt;
+    int response;
+    float size;
+    int octave;
+    float angle;
+};
+#endif
+static_assert(sizeof(KeyPoint) == sizeof(orbfe_keypoint), "KeyPoint must stay memcpy-compatible with orbfe_keypoint");
+
+namespace orbfe_detail {
+inline void check(int rc, const orbfe_handle* h, const char* where)
+{
+    // The reference aborts the process on device errors (include/cuda/HelperCuda.h:44-50); the adaptor
+    // throws instead so the caller can decide.
+    if (rc != ORBFE_OK)
+        throw std::runtime_error(std::string(where) + ": " + orbfe_status_string(rc) + " " + (h ? orbfe_last_error(h) : ""));
+}
+}  // namespace orbfe_detail
+
+struct GrayImageView {  // stand-in for cv::cuda::HostMem when OpenCV is absent
+    const uint8_t* data;
+    int pitch;
+};
+
+class ORBextractor {
+public:
+    // include/ORBextractor.h:55-56
+    ORBextractor(int nFeatures, int nFastFeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                 int imageWidth, int imageHeight, int deviceId = 0)
+    {
+        orbfe_params p{nFeatures, nFastFeatures, scaleFactor, nlevels, iniThFAST, minThFAST, imageWidth, imageHeight, deviceId, 1};
+        orbfe_detail::check(orbfe_create(&p, &h_), nullptr, "orbfe_create");
+        const int n = nlevels;
+        mvScaleFactor.resize(n);
+        mvInvScaleFactor.resize(n);
+        mvLevelSigma2.resize(n);
+        mvInvLevelSigma2.resize(n);
+        orbfe_detail::check(orbfe_get_scale_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                                                   mvInvLevelSigma2.data()), h_, "orbfe_get_scale_tables");
+        cap_ = orbfe_max_keypoints(h_);
+        width_ = imageWidth;
+        height_ = imageHeight;
+    }
+    ~ORBextractor() { orbfe_destroy(h_); }
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // include/ORBextractor.h:62 -- nullopt when no keypoint was found (src/ORBextractor.cc:494-496)
+    std::optional<std::tuple<std::shared_ptr<std::vector<KeyPoint>>, std::vector<uint8_t>>> extractFeatures(const GrayImageView& im)
+    {
+        auto keys = std::make_shared<std::vector<KeyPoint>>(cap_);
+        std::vector<uint8_t> desc((size_t)cap_ * ORBFE_DESC_BYTES);
+        int n = 0;
+        orbfe_detail::check(orbfe_extract(h_, im.data, im.pitch, reinterpret_cast<orbfe_keypoint*>(keys->data()), desc.data(), &n,
+                                          nullptr), h_, "orbfe_extract");
+        if (n == 0) return std::nullopt;
+        keys->resize(n);
+        desc.resize((size_t)n * ORBFE_DESC_BYTES);
+        return {{keys, std::move(desc)}};
+    }
+
+#ifdef ORBFE_WITH_OPENCV
+    // the exact reference signature
+    std::optional<std::tuple<std::shared_ptr<std::vector<KeyPoint>>, cv::cuda::HostMem>> extractFeatures(const cv::cuda::HostMem& im_managed)
+    {
+        const cv::Mat im = im_managed.createMatHeader();
+        auto r = extractFeatures(GrayImageView{im.data, (int)im.step});
+        if (!r) return std::nullopt;
+        auto& [keys, desc] = *r;
+        cv::cuda::HostMem d((int)keys->size(), 32, CV_8UC1, cv::cuda::HostMem::AllocType::SHARED);
+        cv::Mat dm = d.createMatHeader();
+        for (int i = 0; i < dm.rows; i++) std::memcpy(dm.ptr(i), desc.data() + (size_t)i * 32, 32);
+        return {{keys, d}};
+    }
+#endif
+
+    // include/ORBextractor.h:64-92
+    int GetLevels() { return orbfe_get_levels(h_); }
+    float GetScaleFactor() { return orbfe_get_scale_factor(h_); }
+    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // mvImagePyramid / mvBlurredImagePyramid (include/ORBextractor.h:94-95): copy of one level of the last frame
+    std::vector<uint8_t> PyramidLevel(int level, bool blurred, int* w = nullptr, int* h = nullptr)
+    {
+        std::vector<int> lw(GetLevels()), lh(GetLevels());
+        orbfe_detail::check(orbfe_get_level_info(h_, nullptr, lw.data(), lh.data()), h_, "orbfe_get_level_info");
+        std::vector<uint8_t> out((size_t)lw[level] * lh[level]);
+        orbfe_detail::check(orbfe_get_pyramid_level(h_, 0, level, blurred, out.data(), lw[level]), h_, "orbfe_get_pyramid_level");
+        if (w) *w = lw[level];
+        if (h) *h = lh[level];
+        return out;
+    }
+
+    orbfe_handle* handle() { return h_; }
+    int maxKeypoints() const { return cap_; }
+
+private:
+    orbfe_handle* h_ = nullptr;
+    int cap_ = 0, width_ = 0, height_ = 0;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+// All-static like the reference (include/ORBmatcher.h:40-75); the GPU handle is the extractor's.
+class ORBmatcher {
+public:
+    static constexpr int TH_LOW = ORBFE_TH_LOW;
+    static constexpr int TH_HIGH = ORBFE_TH_HIGH;
+    static constexpr size_t HISTO_LENGTH = ORBFE_HISTO_LENGTH;
+
+    // src/ORBmatcher.cc:1375-1391 (rows of the descriptor matrices)
+    static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return orbfe_hamming(a, b); }
+
+    // src/ORBmatcher.cc:31-123.  `F` needs: mNumKeypoints, mvKeysUn (shared_ptr<vector<KeyPoint>>), descriptor
+    // rows via descPtr(F), mvpMapPoints (vector<shared_ptr<MapPoint>>), mvScaleFactors, the static grid members
+    // mnMinX, mnMinY, mfGridElementWidthInv/HeightInv, getFrameGridCols()/Rows().  `MapPoint` needs: mbTrackInView,
+    // mTrackDepth, isBad(), mnTrackScaleLevel, mTrackViewCos, mTrackProjX/Y, GetDescriptor-like descPtr(), Observations().
+    template <class FramePtr, class MapPointPtr, class DescOfFrame, class DescOfMapPoint>
+    static int SearchByProjection(orbfe_handle* h, FramePtr F, const std::vector<MapPointPtr>& vpMapPoints, const float th,
+                                  const bool bFarPoints, const float thFarPoints, const float nnRatio,
+                                  const bool /*checkOrientation: unused by the reference, :31*/, DescOfFrame frameDesc,
+                                  DescOfMapPoint mpDesc)
+    {
+        const int n = F->mNumKeypoints;
+        const int M = (int)vpMapPoints.size();
+        std::vector<orbfe_map_point> mps(M);
+        std::vector<uint8_t> mpd((size_t)M * 32);
+        for (int i = 0; i < M; i++) {
+            const auto& p = vpMapPoints[i];
+            // mbTrackInViewR only exists for the stereo-fisheye case; mono: inView == mbTrackInView (:40-41,49)
+            mps[i] = orbfe_map_point{p->mTrackProjX, p->mTrackProjY, p->mTrackViewCos, p->mTrackDepth, p->mnTrackScaleLevel,
+                                     p->mbTrackInView ? 1 : 0, p->isBad() ? 1 : 0, p->Observations()};
+            std::memcpy(&mpd[(size_t)i * 32], mpDesc(p), 32);
+        }
+        std::vector<int> initObs(n, -1);
+        for (int i = 0; i < n; i++)
+            if (F->mvpMapPoints[i]) initObs[i] = F->mvpMapPoints[i]->Observations();
+        orbfe_frame_view fv{n, reinterpret_cast<const orbfe_keypoint*>(F->mvKeysUn->data()), frameDesc(F),
+                            F->getFrameGridCols(), F->getFrameGridRows(), F->mnMinX, F->mnMinY, F->mfGridElementWidthInv,
+                            F->mfGridElementHeightInv, (int)F->mvScaleFactors.size(), F->mvScaleFactors.data()};
+        std::vector<int> match(n > 0 ? n : 1);
+        int nmatches = 0;
+        orbfe_detail::check(orbfe_match_projection(h, &fv, M, mps.data(), mpd.data(), initObs.data(), th, bFarPoints, thFarPoints,
+                                                   nnRatio, match.data(), &nmatches), h, "orbfe_match_projection");
+        for (int i = 0; i < n; i++)
+            if (match[i] >= 0) F->mvpMapPoints[i] = vpMapPoints[match[i]];  // :113
+        return nmatches;
+    }
+
+    // src/ORBmatcher.cc:133-327.  FeatureVector = std::map<NodeId, std::vector<unsigned>> (DBoW2).  The merge-walk
+    // over the two maps (:161-163,289-301) happens here on the host and is handed over as CSR groups.
+    template <class KeyFramePtr, class FramePtr, class MapPointPtr, class FeatureVector, class DescOfKF, class DescOfFrame>
+    static int SearchByBoW(orbfe_handle* h, KeyFramePtr pKF, FramePtr F, std::vector<MapPointPtr>& vpMapPointMatches,
+                           const FeatureVector& vFeatVecKF, const FeatureVector& vFeatVecF, const float nnRatio,
+                           const bool checkOrientation, DescOfKF kfDesc, DescOfFrame frameDesc)
+    {
+        const auto vpMapPointsKF = pKF->GetMapPointMatches();
+        const int nKF = (int)vpMapPointsKF.size();
+        const int nF = F->mNumKeypoints;
+        vpMapPointMatches.assign(nF, MapPointPtr());
+        std::vector<int> kfOff{0}, kfIdx, fOff{0}, fIdx;
+        auto KFit = vFeatVecKF.begin(), KFend = vFeatVecKF.end();
+        auto Fit = vFeatVecF.begin(), Fend = vFeatVecF.end();
+        while (KFit != KFend && Fit != Fend) {
+            if (KFit->first == Fit->first) {
+                for (unsigned v : KFit->second) kfIdx.push_back((int)v);
+                for (unsigned v : Fit->second) fIdx.push_back((int)v);
+                kfOff.push_back((int)kfIdx.size());
+                fOff.push_back((int)fIdx.size());
+                ++KFit;
+                ++Fit;
+            } else if (KFit->first < Fit->first) {
+                KFit = vFeatVecKF.lower_bound(Fit->first);
+            } else {
+                Fit = vFeatVecF.lower_bound(KFit->first);
+            }
+        }
+        std::vector<uint8_t> hasMP(nKF > 0 ? nKF : 1, 0);
+        std::vector<float> kfAngle(nKF > 0 ? nKF : 1), fAngle(nF > 0 ? nF : 1);
+        for (int i = 0; i < nKF; i++) {
+            hasMP[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();  // :172-176
+            kfAngle[i] = (*pKF->mvKeysUn)[i].angle;
+        }
+        for (int i = 0; i < nF; i++) fAngle[i] = (*F->mvKeysUn)[i].angle;
+        std::vector<int> match(nF > 0 ? nF : 1);
+        int nmatches = 0;
+        orbfe_detail::check(orbfe_match_bow(h, (int)kfOff.size() - 1, kfOff.data(), kfIdx.data(), fOff.data(), fIdx.data(), nKF,
+                                            kfDesc(pKF), kfAngle.data(), hasMP.data(), nF, frameDesc(F), fAngle.data(), nnRatio,
+                                            checkOrientation, match.data(), &nmatches), h, "orbfe_match_bow");
+        for (int j = 0; j < nF; j++)
+            if (match[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[match[j]];  // :241
+        return nmatches;
+    }
+};
+
+}  // namespace ORB_SLAM3

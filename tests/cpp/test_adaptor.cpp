@@ -1,0 +1,89 @@
+// Drives include/orbfe_adaptor.hpp the way src/Frame.cc:178-189 and src/Tracking.cc:1115 drive the
+// reference classes, with light mock Frame / MapPoint types that carry the members those functions read.
+//   usage: test_adaptor <W> <H> <gray.raw> <mps.bin> <M> <out.bin>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "orbfe_adaptor.hpp"
+
+using namespace ORB_SLAM3;
+
+struct MapPoint {
+    bool mbTrackInView = true;
+    float mTrackDepth = 1.f, mTrackViewCos = 1.f, mTrackProjX = 0.f, mTrackProjY = 0.f;
+    int mnTrackScaleLevel = 0, obs = 1;
+    bool bad = false;
+    uint8_t desc[32];
+    bool isBad() const { return bad; }
+    int Observations() const { return obs; }
+};
+
+struct Frame {
+    int mNumKeypoints = 0;
+    std::shared_ptr<std::vector<KeyPoint>> mvKeysUn;
+    std::vector<uint8_t> mDescriptors;
+    std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
+    std::vector<float> mvScaleFactors;
+    float mnMinX = 0, mnMinY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    int cols = 64, rows = 48;
+    int getFrameGridCols() const { return cols; }
+    int getFrameGridRows() const { return rows; }
+};
+
+static std::vector<uint8_t> slurp(const char* p)
+{
+    std::ifstream f(p, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 7) { std::printf("%s\n", orbfe_version()); return 0; }  // link smoke test (no GPU needed)
+    const int W = atoi(argv[1]), H = atoi(argv[2]), M = atoi(argv[5]);
+    const auto img = slurp(argv[3]);
+    const auto mpraw = slurp(argv[4]);  // M x (orbfe_map_point + 32 desc bytes)
+    ORBextractor ex(1000, 40000, 1.2f, 8, 20, 7, W, H);
+    auto r = ex.extractFeatures(GrayImageView{img.data(), W});
+    if (!r) { std::puts("nullopt"); return 2; }
+    auto [keys, desc] = *r;
+
+    auto F = std::make_shared<Frame>();  // Frame::Frame, src/Frame.cc:56-135 (the parts the matcher reads)
+    F->mNumKeypoints = (int)keys->size();
+    F->mvKeysUn = keys;
+    F->mDescriptors = desc;
+    F->mvpMapPoints.assign(keys->size(), nullptr);
+    F->mvScaleFactors = ex.GetScaleFactors();
+    F->mfGridElementWidthInv = (float)F->cols / (float)(W - 0.f);
+    F->mfGridElementHeightInv = (float)F->rows / (float)(H - 0.f);
+
+    std::vector<std::shared_ptr<MapPoint>> mps;
+    const size_t rec = sizeof(orbfe_map_point) + 32;
+    for (int i = 0; i < M; i++) {
+        orbfe_map_point q;
+        std::memcpy(&q, mpraw.data() + i * rec, sizeof q);
+        auto p = std::make_shared<MapPoint>();
+        p->mTrackProjX = q.proj_x; p->mTrackProjY = q.proj_y; p->mTrackViewCos = q.view_cos; p->mTrackDepth = q.track_depth;
+        p->mnTrackScaleLevel = q.level; p->mbTrackInView = q.in_view; p->bad = q.bad; p->obs = q.observations;
+        std::memcpy(p->desc, mpraw.data() + i * rec + sizeof q, 32);
+        mps.push_back(p);
+    }
+    const int nm = ORBmatcher::SearchByProjection(
+        ex.handle(), F, mps, 20.f, false, 0.f, 0.85f, false, [](const std::shared_ptr<Frame>& f) { return f->mDescriptors.data(); },
+        [](const std::shared_ptr<MapPoint>& p) { return (const uint8_t*)p->desc; });
+
+    std::ofstream o(argv[6], std::ios::binary);
+    const int n = (int)keys->size();
+    o.write((const char*)&n, 4);
+    o.write((const char*)&nm, 4);
+    o.write((const char*)keys->data(), (std::streamsize)n * sizeof(KeyPoint));
+    o.write((const char*)desc.data(), (std::streamsize)n * 32);
+    for (int i = 0; i < n; i++) {
+        int idx = -1;
+        for (int j = 0; j < M && F->mvpMapPoints[i]; j++)
+            if (mps[j] == F->mvpMapPoints[i]) { idx = j; break; }
+        o.write((const char*)&idx, 4);
+    }
+    std::printf("adaptor ok: %d keypoints, %d matches, levels=%d scale=%g\n", n, nm, ex.GetLevels(), ex.GetScaleFactor());
+    return 0;
+}

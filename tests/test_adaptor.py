@@ -1,0 +1,52 @@
+"""The reference-signature C++ adaptor (include/orbfe_adaptor.hpp): compiles + links without a GPU,
+and on the GPU box reproduces the oracle through the ORBextractor / ORBmatcher classes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "orb_slam3_v1.0_amd", "csrc")
+BIN = os.path.join(ROOT, "tests", "cpp", "test_adaptor.bin")
+
+
+def _build():
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_adaptor.cpp"), "-o", BIN, "-L", CSRC, "-lorbfe",
+                           "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_adaptor_compiles_and_links(built):
+    _build()
+    out = subprocess.check_output([BIN]).decode()
+    assert "gfx950" in out
+
+
+@pytest.mark.gpu
+def test_adaptor_matches_oracle(built, tmp_path):
+    import match_scenarios as S
+    import oracle_py as O
+    import orbfe
+    from orbfe import synth
+    _build()
+    W, H, M = 752, 480, 1500
+    img = synth.frame(W, H, 4)
+    e = O.Extractor(1000, 40000, 1.2, 8, 20, 7, W, H)
+    kp_r, desc_r, _ = e.extract(img)
+    names = ("projX", "projY", "viewCos", "trackDepth", "level", "inView", "bad", "observations")
+    mps, mpd, _ = S.projection_scenario(kp_r, desc_r, M, 3, O.MP_DTYPE, names, e.nLevels)
+    fv = O.make_frame_view(kp_r, desc_r, 64, 48, 0.0, 0.0, float(W), float(H), e.scaleFactors)
+    n_ref, out_ref = O.search_by_projection(fv, mps, mpd, None, 20.0, 0.85)
+    (tmp_path / "g.raw").write_bytes(img.tobytes())
+    rec = np.zeros(M, np.dtype([("mp", O.MP_DTYPE), ("d", np.uint8, 32)]))
+    rec["mp"], rec["d"] = mps, mpd
+    (tmp_path / "m.bin").write_bytes(rec.tobytes())
+    subprocess.check_call([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "m.bin"), str(M), str(tmp_path / "o.bin")])
+    raw = (tmp_path / "o.bin").read_bytes()
+    n, nm = np.frombuffer(raw[:8], np.int32)
+    kp = np.frombuffer(raw[8:8 + 24 * n], orbfe.KP_DTYPE)
+    desc = np.frombuffer(raw[8 + 24 * n:8 + 56 * n], np.uint8).reshape(n, 32)
+    match = np.frombuffer(raw[8 + 56 * n:], np.int32)
+    assert n == len(kp_r) and kp.tobytes() == kp_r.tobytes() and np.array_equal(desc, desc_r)
+    assert nm == n_ref and np.array_equal(match, out_ref)
