@@ -31,26 +31,15 @@
 
 #include "launch.h"
 #include "device_math.h"
+#include "fast_common.h"
 
 namespace orbfe {
 
-constexpr int kFastTW = 64, kFastTH = 32;
-constexpr int kImgW = kFastTW + 8, kImgH = kFastTH + 8;   // 72 x 40 staged pixels
+constexpr int kImgW = kFastTW + 8, kImgH = kFastTH + 8;   // 72 x 40 staged pixels (tile size: fast_common.h)
 constexpr int kScW = kFastTW + 2, kScH = kFastTH + 2;     // 66 x 34 scores
 constexpr int kScPitch = 68;
 constexpr int kMaxTileCand = (kFastTW / 2) * (kFastTH / 2);  // strict 8-neighbour maxima: <= 1 per 2x2
 constexpr int kTmpH = kFastTH + 4;                        // 36 rows of horizontal blur sums
-
-// 16-bit circular mask contains >= 9 contiguous ones (== c_table lookup, Fast_gpu.cu:187-191)
-__device__ __forceinline__ bool arc9(uint32_t m)
-{
-    uint32_t m2 = m | (m << 16);
-    uint32_t r = m2 & (m2 >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= m2 >> 8;
-    return (r & 0xffffu) != 0;
-}
 
 // max over the 16 circular 9-arcs of the minimum of a[] over the arc
 __device__ __forceinline__ int arc_max_min(const int (&a)[16])
@@ -141,8 +130,10 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                                                         const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
                                                         int gray0Pitch, int gray0Aligned4,
                                                         uint8_t* __restrict__ ws, uint32_t* __restrict__ cand,
-                                                        uint32_t* __restrict__ counters)
+                                                        uint32_t* __restrict__ counters,
+                                                        uint32_t* __restrict__ tileRows)
 {
+    __shared__ uint32_t sRow[kFastTH];  // pre-NMS corners per tile row: low-pass count | high-pass count << 16
     __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH][kImgW];
     __shared__ __attribute__((aligned(16))) uint16_t sTmp[kTmpH][kFastTW];
     __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH][kScPitch];
@@ -183,6 +174,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int lane = tid & 63;
     if (tid < 4) sCnt[tid] = 0;
     if (tid < 2) sQ[tid] = 0;
+    if (tid < kFastTH) sRow[tid] = 0;
 
     // ---- stage the 72 x 40 tile (origin x0-4, y0-4); pixels outside the level follow
     //      BORDER_REFLECT_101 (needed by the blur; FAST never looks at them) ----
@@ -372,6 +364,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                 if (pre) {
                     s = sScore[sy][sx];
                     hi = s >= iniTh;
+                    atomicAdd(&sRow[oy], hi ? 0x10001u : 1u);  // only read by the exact-cap path of the quadtree kernel
                     keep = s > sScore[sy - 1][sx - 1] && s > sScore[sy - 1][sx] && s > sScore[sy - 1][sx + 1] &&
                            s > sScore[sy][sx - 1] && s > sScore[sy][sx + 1] && s > sScore[sy + 1][sx - 1] &&
                            s > sScore[sy + 1][sx] && s > sScore[sy + 1][sx + 1];
@@ -399,6 +392,9 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     __syncthreads();
 
     }  // MODE & 2
+
+    // per-tile-row pre-NMS counts (128 B per tile, plain coalesced store; zero when FAST is ablated)
+    if (tid < kFastTH) tileRows[((size_t)f * P->totalTiles + tile) * kFastTH + tid] = sRow[tid];
 
     uint32_t* cnt = counters + ((size_t)f * nL + l) * kCntWords;
     const uint32_t nTile = sCnt[0];
@@ -429,7 +425,7 @@ void fast_tiles_for(int w, int h, int* tx, int* ty)
 
 void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
                       size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws, uint32_t* cand,
-                      uint32_t* counters)
+                      uint32_t* counters, uint32_t* tileRows)
 {
     dim3 block(256);
     dim3 grid(frames, totalTiles);
@@ -439,7 +435,7 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
     }();
 #define ORBFE_LAUNCH_FB(M)                                                                               \
     hipLaunchKernelGGL(fast_blur_kernel<M>, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch, \
-                       gray0Aligned4, ws, cand, counters)
+                       gray0Aligned4, ws, cand, counters, tileRows)
     switch (mode) {
     case 0: ORBFE_LAUNCH_FB(0); break;
     case 1: ORBFE_LAUNCH_FB(1); break;

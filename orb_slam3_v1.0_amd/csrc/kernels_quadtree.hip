@@ -22,6 +22,7 @@
 //    gets weight (score >= iniTh) + (retry pass taken && inside the low-list cap).
 //  * Best point per node: max response, ties -> first in vKeys order == smallest raster key.
 #include "launch.h"
+#include "fast_common.h"
 
 namespace orbfe {
 
@@ -78,12 +79,76 @@ __device__ __forceinline__ int block_excl_scan(int v, int& total, int* sWave)
     return base + incl - v;
 }
 
+// Exclusive raster-key bound of one FAST pass' pre-NMS cap: key of the nFast-th corner (raster order)
+// of this level, plus one.  The cutoff row comes from the per-tile-row counts the FAST kernel
+// stored; the cutoff column from re-running the segment test along that single row.  Block-wide,
+// every thread returns the same value.  Only called when the level has more than nFast corners.
+__device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const LevelDesc& L, int f, int l, bool high,
+                                    int nFast, const uint8_t* __restrict__ gray0, size_t gray0FrameStride, int gray0Pitch,
+                                    const uint8_t* __restrict__ ws, const uint32_t* __restrict__ tileRows, int* sWave,
+                                    int* sRed)
+{
+    const int tid = threadIdx.x;
+    const uint32_t* tr = tileRows + ((size_t)f * P->totalTiles + L.tileBase) * kFastTH;
+    if (tid == 0) { sRed[0] = -1; sRed[1] = 0; sRed[2] = -1; }
+    __syncthreads();
+    int carry = 0;
+    for (int base = 0; base < L.h; base += kQtThreads) {  // row where the running corner count reaches nFast
+        const int y = base + tid;
+        int c = 0;
+        if (y < L.h) {
+            const int ty = y / kFastTH, r = y % kFastTH;
+            for (int tx = 0; tx < L.tilesX; tx++) {
+                const uint32_t v = tr[(size_t)(ty * L.tilesX + tx) * kFastTH + r];
+                c += high ? (int)(v >> 16) : (int)(v & 0xffffu);
+            }
+        }
+        int tot;
+        const int ex = block_excl_scan(c, tot, sWave) + carry;
+        if (c > 0 && ex < nFast && ex + c >= nFast) { sRed[0] = y; sRed[1] = nFast - ex; }  // exactly one thread
+        carry += tot;
+        __syncthreads();
+        if (sRed[0] >= 0) break;
+    }
+    const int ys = sRed[0], q = sRed[1];
+    if (ys < 0) return kKeyInf;
+    const uint8_t* img;
+    int pitch;
+    if (l == 0) {
+        img = gray0 + (size_t)f * gray0FrameStride;
+        pitch = gray0Pitch;
+    } else {
+        img = ws + L.imgOff + (size_t)f * L.imgFrameStride;
+        pitch = L.pitch;
+    }
+    const int th = high ? P->iniTh : P->minTh;  // corner of the pass <=> score >= its threshold
+    carry = 0;
+    for (int base = 0; base < L.w; base += kQtThreads) {  // the q-th corner of that row
+        const int x = base + tid;
+        int flag = 0;
+        if (x > kEdge && x < L.w - kEdge) flag = corner_at_global(img, pitch, x, ys, th) ? 1 : 0;
+        int tot;
+        const int ex = block_excl_scan(flag, tot, sWave) + carry;
+        if (flag && ex + 1 == q) sRed[2] = x;
+        carry += tot;
+        __syncthreads();
+        if (sRed[2] >= 0) break;
+    }
+    const int xs = sRed[2];
+    __syncthreads();
+    if (xs < 0) return kKeyInf;  // cannot happen: the row holds at least q corners
+    return (((uint32_t)ys << kCoordBits) | (uint32_t)xs) + 1u;
+}
+
 template <int NC>
 __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc* __restrict__ P,
                                                              const uint32_t* __restrict__ cand,
                                                              uint16_t* __restrict__ nodeOfAll,
                                                              uint32_t* __restrict__ counters,
-                                                             uint32_t* __restrict__ lvlKp)
+                                                             uint32_t* __restrict__ lvlKp,
+                                                             const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
+                                                             int gray0Pitch, const uint8_t* __restrict__ ws,
+                                                             const uint32_t* __restrict__ tileRows)
 {
     constexpr int IPT = NC / kQtThreads;  // nodes per thread in node-parallel steps
     static_assert(NC % kQtThreads == 0, "NC must be a multiple of the block size");
@@ -112,30 +177,50 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
     const int N = L.nFeatures;
     const int nFast = P->nFast;
     const int iniTh = P->iniTh;
-    int cL = (int)min(cnt[kCntCand], (uint32_t)L.candCap);
-    const int cH = (int)cnt[kCntHigh];
+    const int nAll = (int)min(cnt[kCntCand], (uint32_t)L.candCap);  // NMS survivors stored by the FAST kernel
+    // ---- the reference's caps (S2b: raster-first entries survive) ----
+    // (i) GpuFast::detect keeps only the first maxKeypoints PRE-NMS corners of a pass
+    //     (src/cuda/Fast_gpu.cu:278-281,377); a survivor counts for a pass iff its raster key is below the
+    //     key of that pass' nFast-th corner.  Rare: only when a level has more than nFast corners.
+    uint32_t cutHi = kKeyInf, cutLo = kKeyInf;
+    int cH = (int)cnt[kCntHigh];
+    if ((int)cnt[kCntPreHigh] > nFast) {
+        cutHi = pre_nms_cut_key(P, L, f, l, true, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
+        int c = 0;
+        for (int p = tid; p < nAll; p += kQtThreads) c += cand_score(C[p]) >= iniTh && cand_key(C[p]) < cutHi;
+        block_excl_scan(c, cH, sWave);
+    }
     // retry rule, src/ORBextractor.cc:440,463-465 (unsigned diff, double compare)
     const unsigned diff = (unsigned)nFast - (unsigned)cH;
     const bool retry = (double)diff > 0.25 * (double)nFast;
-    uint32_t keyCut = kKeyInf;
+    int cL = nAll;
+    if (retry && (int)cnt[kCntPreLow] > nFast) {
+        cutLo = pre_nms_cut_key(P, L, f, l, false, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
+        int c = 0;
+        for (int p = tid; p < nAll; p += kQtThreads) c += cand_key(C[p]) < cutLo;
+        block_excl_scan(c, cL, sWave);
+    }
+    // (ii) high + low lists together are capped at nFast by trimming the low list's tail (:470-473)
+    uint32_t keyCut = cutLo;
     int lowKept = 0;
     if (retry && cL > 0) {
         lowKept = cL;
-        if (cH + cL > nFast) lowKept = max(nFast - cH, 0);  // :470-473, raster-first entries survive (S2b)
+        if (cH + cL > nFast) lowKept = max(nFast - cH, 0);
     }
     if (retry && lowKept < cL) {
-        // rare path: smallest key K with #{key < K} >= lowKept  (binary search over the 24-bit key)
-        uint32_t lo = 0, hi = kKeyInf;  // invariant: count(key < lo) < lowKept+? ; find min K: count(key<K) >= lowKept
+        // smallest key K with #{key < K} >= lowKept  (binary search over the 24-bit key)
+        uint32_t lo = 0, hi = kKeyInf;
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             int c = 0;
-            for (int p = tid; p < cL; p += kQtThreads) c += cand_key(C[p]) < mid;
+            for (int p = tid; p < nAll; p += kQtThreads) c += cand_key(C[p]) < mid;
             int tot;
             block_excl_scan(c, tot, sWave);
             if (tot >= lowKept) hi = mid; else lo = mid + 1;
         }
-        keyCut = lo;
+        keyCut = min(lo, cutLo);
     }
+    cL = nAll;  // loops below run over every stored survivor; the weights apply the cuts
     const int totalPts = cH + lowKept;
     if (totalPts == 0) {
         if (tid == 0) cnt[kCntKp] = 0;
@@ -146,7 +231,7 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
         return;
     }
 
-#define PT_WEIGHT(cw) ((int)(cand_score(cw) >= iniTh) + (int)(retry && cand_key(cw) < keyCut))
+#define PT_WEIGHT(cw) ((int)(cand_score(cw) >= iniTh && cand_key(cw) < cutHi) + (int)(retry && cand_key(cw) < keyCut))
 
     // ---- initial nodes, :231-274 ----
     const int nIni = L.nIni;
@@ -414,14 +499,18 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
 int quadtree_node_capacity(int variant) { return variant == 0 ? 512 : 2048; }
 
 void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
-                     const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp)
+                     const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp,
+                     const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws,
+                     const uint32_t* tileRows)
 {
     dim3 block(kQtThreads);
     dim3 grid(frames, nLevels);
     if (maxNodeCap <= 512)
-        hipLaunchKernelGGL(quadtree_kernel<512>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp);
+        hipLaunchKernelGGL(quadtree_kernel<512>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
+                           gray0FrameStride, gray0Pitch, ws, tileRows);
     else
-        hipLaunchKernelGGL(quadtree_kernel<2048>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp);
+        hipLaunchKernelGGL(quadtree_kernel<2048>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
+                           gray0FrameStride, gray0Pitch, ws, tileRows);
 }
 
 }  // namespace orbfe

@@ -13,12 +13,14 @@ void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFram
 void fast_tiles_for(int w, int h, int* tx, int* ty);
 void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
                       size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws, uint32_t* cand,
-                      uint32_t* counters);
+                      uint32_t* counters, uint32_t* tileRows);
 
 // kernels_quadtree.hip
 int quadtree_node_capacity(int variant);
 void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
-                     const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp);
+                     const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp,
+                     const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws,
+                     const uint32_t* tileRows);
 
 // kernels_desc.hip
 void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const PipelineDesc* dP, const uint8_t* gray0,

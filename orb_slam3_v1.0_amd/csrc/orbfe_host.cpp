@@ -48,6 +48,7 @@ struct orbfe_handle {
     size_t candWordsPerBatch = 0;
     uint32_t* dCounters = nullptr;  // [frame][level][kCntWords]
     uint32_t* dLvlKp = nullptr;     // [frame][kpCapFrame]
+    uint32_t* dTileRows = nullptr;  // [frame][FAST tile][32] pre-NMS corner counts per tile row
     uint32_t* dTabs = nullptr;      // resize tables
     float* dSf = nullptr;           // mvScaleFactor on the device (batched matcher)
 
@@ -119,7 +120,7 @@ void destroy_impl(orbfe_handle* h)
         for (auto& e : set)
             if (e) (void)hipEventDestroy(e);
     match_scratch_free(h->match);
-    void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTabs,
+    void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTileRows, h->dTabs,
                      h->dSf, h->dIn, h->dKp, h->dDesc, h->dN, h->dPer};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
@@ -293,6 +294,7 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     CREATE_CHK(hipMalloc(&h->dNodeOf, candOff * sizeof(uint16_t)));
     CREATE_CHK(hipMalloc(&h->dCounters, B * nL * kCntWords * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dLvlKp, B * (size_t)P.kpCapFrame * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(&h->dTileRows, B * (size_t)P.totalTiles * 32 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dTabs, tabs.size() * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dSf, kMaxLevels * sizeof(float)));
     CREATE_CHK(hipMemcpy(h->dSf, h->sf, kMaxLevels * sizeof(float), hipMemcpyHostToDevice));
@@ -414,9 +416,11 @@ int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t fr
                       D.pitch, h->dTabs + D.xtabOff, h->dTabs + D.ytabOff);
     }
     if (ev) HIPCHK(h, hipEventRecord(ev[1], s));
-    launch_fast_blur(s, batch, P.totalTiles, h->dP, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters);
+    launch_fast_blur(s, batch, P.totalTiles, h->dP, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters,
+                     h->dTileRows);
     if (ev) HIPCHK(h, hipEventRecord(ev[2], s));
-    launch_quadtree(s, batch, nL, h->maxNodeCap, h->dP, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp);
+    launch_quadtree(s, batch, nL, h->maxNodeCap, h->dP, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, d_gray, frame_stride,
+                    pitch, h->ws, h->dTileRows);
     if (ev) HIPCHK(h, hipEventRecord(ev[3], s));
     launch_orient_brief(s, batch, P.kpCapFrame, h->dP, d_gray, frame_stride, pitch, h->ws, h->dCounters, h->dLvlKp,
                         d_kp, d_desc, d_n, d_per);

@@ -14,6 +14,10 @@ CONFIGS = {
     "c5_1024sq": (1500, 100000, 1.2, 12, 20, 7, 1024, 1024),
     "c4_1280x720": (2000, 100000, 1.2, 8, 20, 7, 1280, 720),
     "ref_node_1level": (10000, 16000, 2.0, 1, 100, 80, 614, 460),  # mono_inertial_node.cpp:87-93
+    # pre-NMS / final caps active (S2b): SURVEY's default nFast = 16 * nFeatures, and a tight one
+    "c1_nfast16k": (1000, 16000, 1.2, 8, 20, 7, 752, 480),
+    "cap_tight": (500, 2500, 1.2, 6, 20, 7, 333, 251),
+    "cap_hi": (300, 900, 1.2, 4, 9, 7, 320, 240),
 }
 
 
@@ -68,7 +72,7 @@ def test_stages_match_oracle(built, cfg):
     assert np.array_equal(desc, desc_r)
 
 
-@pytest.mark.parametrize("cfg", ["c5_1024sq", "c4_1280x720", "ref_node_1level"])
+@pytest.mark.parametrize("cfg", ["c5_1024sq", "c4_1280x720", "c1_nfast16k", "cap_tight", "cap_hi", "ref_node_1level"])
 def test_extract_bit_exact(built, cfg):
     ex = _mk(cfg)
     ref = O.Extractor(*CONFIGS[cfg])
