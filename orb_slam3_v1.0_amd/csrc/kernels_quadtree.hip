@@ -140,7 +140,10 @@ __device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const Le
     return (((uint32_t)ys << kCoordBits) | (uint32_t)xs) + 1u;
 }
 
-template <int NC>
+// bytes of the per-block HBM slab of the GLOBAL variant (see the carve in the kernel)
+__host__ __device__ constexpr size_t qt_scratch_bytes(int nc) { return (size_t)nc * (8 + 8 + 8 + 4 + 4 + 16 + 4 + 4 + 4 + 1 + 1); }
+
+template <int NC, bool GLOBAL>
 __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc* __restrict__ P,
                                                              const uint32_t* __restrict__ cand,
                                                              uint16_t* __restrict__ nodeOfAll,
@@ -148,20 +151,50 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
                                                              uint32_t* __restrict__ lvlKp,
                                                              const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
                                                              int gray0Pitch, const uint8_t* __restrict__ ws,
-                                                             const uint32_t* __restrict__ tileRows)
+                                                             const uint32_t* __restrict__ tileRows,
+                                                             uint8_t* __restrict__ scratch)
 {
     constexpr int IPT = NC / kQtThreads;  // nodes per thread in node-parallel steps
     static_assert(NC % kQtThreads == 0, "NC must be a multiple of the block size");
 
-    __shared__ Box sBox[2][NC];
-    __shared__ int sCnt[2][NC];
-    __shared__ int sCC[NC * 4];       // child counts, then child new positions
-    __shared__ int sKeep[NC];         // new position of a non-split node
-    __shared__ int sS[NC];            // flat-map offset of a split node's first child
-    __shared__ uint8_t sSplit[NC];
-    __shared__ uint8_t sNch[NC];
-    __shared__ unsigned long long sKey[NC];
-    __shared__ int sProc[NC];         // sorted phase: rank -> node
+    // Node tables: LDS for the usual per-level budgets (<= 2048 nodes); for the reference's large
+    // configurations (e.g. 10000 features in one level, mono_inertial_node.cpp:87-93) the same
+    // tables live in an HBM scratch slab per block (L2-resident, slower, same algorithm).
+    Box* sBox[2];
+    int* sCnt[2];
+    int* sCC;                         // child counts, then child new positions
+    int* sKeep;                       // new position of a non-split node
+    int* sS;                          // flat-map offset of a split node's first child
+    uint8_t* sSplit;
+    uint8_t* sNch;
+    unsigned long long* sKey;
+    int* sProc;                       // sorted phase: rank -> node
+    if constexpr (!GLOBAL) {
+        __shared__ Box lBox[2][NC];
+        __shared__ int lCnt[2][NC];
+        __shared__ int lCC[NC * 4];
+        __shared__ int lKeep[NC];
+        __shared__ int lS[NC];
+        __shared__ uint8_t lSplit[NC];
+        __shared__ uint8_t lNch[NC];
+        __shared__ unsigned long long lKey[NC];
+        __shared__ int lProc[NC];
+        sBox[0] = lBox[0]; sBox[1] = lBox[1]; sCnt[0] = lCnt[0]; sCnt[1] = lCnt[1];
+        sCC = lCC; sKeep = lKeep; sS = lS; sSplit = lSplit; sNch = lNch; sKey = lKey; sProc = lProc;
+    } else {
+        uint8_t* base = scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * qt_scratch_bytes(NC);
+        sKey = reinterpret_cast<unsigned long long*>(base); base += (size_t)NC * 8;
+        sBox[0] = reinterpret_cast<Box*>(base); base += (size_t)NC * 8;
+        sBox[1] = reinterpret_cast<Box*>(base); base += (size_t)NC * 8;
+        sCnt[0] = reinterpret_cast<int*>(base); base += (size_t)NC * 4;
+        sCnt[1] = reinterpret_cast<int*>(base); base += (size_t)NC * 4;
+        sCC = reinterpret_cast<int*>(base); base += (size_t)NC * 16;
+        sKeep = reinterpret_cast<int*>(base); base += (size_t)NC * 4;
+        sS = reinterpret_cast<int*>(base); base += (size_t)NC * 4;
+        sProc = reinterpret_cast<int*>(base); base += (size_t)NC * 4;
+        sSplit = base; base += NC;
+        sNch = base;
+    }
     __shared__ int sWave[kQtThreads / 64];
     __shared__ int sRed[4];
 
@@ -496,21 +529,40 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
 #undef PT_WEIGHT
 }
 
-int quadtree_node_capacity(int variant) { return variant == 0 ? 512 : 2048; }
+// node-table capacity the launcher picks for a given per-level maximum (0 == unsupported)
+int quadtree_node_capacity(int maxNodeCap)
+{
+    const int caps[] = {512, 2048, 8192, 32768, 65536};
+    for (int c : caps)
+        if (maxNodeCap <= c && maxNodeCap <= 65535) return c;  // node ids are u16
+    return 0;
+}
+
+// bytes of HBM scratch one (frame, level) block needs (0 for the LDS variants)
+size_t quadtree_scratch_bytes_per_block(int maxNodeCap)
+{
+    const int nc = quadtree_node_capacity(maxNodeCap);
+    return nc > 2048 ? qt_scratch_bytes(nc) : 0;
+}
 
 void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
                      const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp,
                      const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws,
-                     const uint32_t* tileRows)
+                     const uint32_t* tileRows, uint8_t* scratch)
 {
     dim3 block(kQtThreads);
     dim3 grid(frames, nLevels);
-    if (maxNodeCap <= 512)
-        hipLaunchKernelGGL(quadtree_kernel<512>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
-                           gray0FrameStride, gray0Pitch, ws, tileRows);
-    else
-        hipLaunchKernelGGL(quadtree_kernel<2048>, grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
-                           gray0FrameStride, gray0Pitch, ws, tileRows);
+#define ORBFE_QT(NCV, GLB)                                                                                        \
+    hipLaunchKernelGGL((quadtree_kernel<NCV, GLB>), grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0, \
+                       gray0FrameStride, gray0Pitch, ws, tileRows, scratch)
+    switch (quadtree_node_capacity(maxNodeCap)) {
+    case 512: ORBFE_QT(512, false); break;
+    case 2048: ORBFE_QT(2048, false); break;
+    case 8192: ORBFE_QT(8192, true); break;
+    case 32768: ORBFE_QT(32768, true); break;
+    default: ORBFE_QT(65536, true); break;
+    }
+#undef ORBFE_QT
 }
 
 }  // namespace orbfe

@@ -16,11 +16,12 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
                       uint32_t* counters, uint32_t* tileRows);
 
 // kernels_quadtree.hip
-int quadtree_node_capacity(int variant);
+int quadtree_node_capacity(int maxNodeCap);
+size_t quadtree_scratch_bytes_per_block(int maxNodeCap);
 void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
                      const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp,
                      const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws,
-                     const uint32_t* tileRows);
+                     const uint32_t* tileRows, uint8_t* scratch);
 
 // kernels_desc.hip
 void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const PipelineDesc* dP, const uint8_t* gray0,

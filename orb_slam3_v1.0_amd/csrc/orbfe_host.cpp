@@ -49,6 +49,7 @@ struct orbfe_handle {
     uint32_t* dCounters = nullptr;  // [frame][level][kCntWords]
     uint32_t* dLvlKp = nullptr;     // [frame][kpCapFrame]
     uint32_t* dTileRows = nullptr;  // [frame][FAST tile][32] pre-NMS corner counts per tile row
+    uint8_t* dQtScratch = nullptr;  // node tables of the large-N quadtree variant, [level][frame] slabs
     uint32_t* dTabs = nullptr;      // resize tables
     float* dSf = nullptr;           // mvScaleFactor on the device (batched matcher)
 
@@ -120,7 +121,7 @@ void destroy_impl(orbfe_handle* h)
         for (auto& e : set)
             if (e) (void)hipEventDestroy(e);
     match_scratch_free(h->match);
-    void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTileRows, h->dTabs,
+    void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTileRows, h->dQtScratch, h->dTabs,
                      h->dSf, h->dIn, h->dKp, h->dDesc, h->dN, h->dPer};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
@@ -261,7 +262,7 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
         tabOff += align_up((size_t)L.h, 4);
         h->maxNodeCap = std::max(h->maxNodeCap, L.nodeCap);
     }
-    if (status == ORBFE_OK && h->maxNodeCap > quadtree_node_capacity(1)) status = ORBFE_ERR_UNSUPPORTED;
+    if (status == ORBFE_OK && quadtree_node_capacity(h->maxNodeCap) == 0) status = ORBFE_ERR_UNSUPPORTED;  // > 65535 nodes/level
     if (status != ORBFE_OK) {
         delete h;
         return status;
@@ -295,6 +296,8 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     CREATE_CHK(hipMalloc(&h->dCounters, B * nL * kCntWords * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dLvlKp, B * (size_t)P.kpCapFrame * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dTileRows, B * (size_t)P.totalTiles * 32 * sizeof(uint32_t)));
+    if (quadtree_scratch_bytes_per_block(h->maxNodeCap))
+        CREATE_CHK(hipMalloc(&h->dQtScratch, quadtree_scratch_bytes_per_block(h->maxNodeCap) * B * nL));
     CREATE_CHK(hipMalloc(&h->dTabs, tabs.size() * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dSf, kMaxLevels * sizeof(float)));
     CREATE_CHK(hipMemcpy(h->dSf, h->sf, kMaxLevels * sizeof(float), hipMemcpyHostToDevice));
@@ -420,7 +423,7 @@ int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t fr
                      h->dTileRows);
     if (ev) HIPCHK(h, hipEventRecord(ev[2], s));
     launch_quadtree(s, batch, nL, h->maxNodeCap, h->dP, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, d_gray, frame_stride,
-                    pitch, h->ws, h->dTileRows);
+                    pitch, h->ws, h->dTileRows, h->dQtScratch);
     if (ev) HIPCHK(h, hipEventRecord(ev[3], s));
     launch_orient_brief(s, batch, P.kpCapFrame, h->dP, d_gray, frame_stride, pitch, h->ws, h->dCounters, h->dLvlKp,
                         d_kp, d_desc, d_n, d_per);

@@ -18,6 +18,8 @@ CONFIGS = {
     "c1_nfast16k": (1000, 16000, 1.2, 8, 20, 7, 752, 480),
     "cap_tight": (500, 2500, 1.2, 6, 20, 7, 333, 251),
     "cap_hi": (300, 900, 1.2, 4, 9, 7, 320, 240),
+    "ref_gnss_6level": (50000, 86000, 1.2, 6, 40, 35, 752, 480),  # mono_inertial_gnss_node.cpp:96-101
+    "dense_1level": (10000, 60000, 1.2, 1, 12, 7, 752, 480),       # > 2048 nodes actually reached in one level
 }
 
 
@@ -72,7 +74,7 @@ def test_stages_match_oracle(built, cfg):
     assert np.array_equal(desc, desc_r)
 
 
-@pytest.mark.parametrize("cfg", ["c5_1024sq", "c4_1280x720", "c1_nfast16k", "cap_tight", "cap_hi", "ref_node_1level"])
+@pytest.mark.parametrize("cfg", ["c5_1024sq", "c4_1280x720", "c1_nfast16k", "cap_tight", "cap_hi", "ref_node_1level", "ref_gnss_6level", "dense_1level"])
 def test_extract_bit_exact(built, cfg):
     ex = _mk(cfg)
     ref = O.Extractor(*CONFIGS[cfg])
