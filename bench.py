@@ -153,8 +153,8 @@ def main():
     gather = world > 1 and not a.no_gather
     if gather:
         pack = torch.zeros((B, cap, 60), dtype=torch.uint8, device=dev)  # kp 24 + desc 32 + match 4
-        g_out = torch.zeros((world, B, cap, 60), dtype=torch.uint8, device=dev)
-        g_n = torch.zeros((world, B), dtype=torch.int32, device=dev)
+        g_out = torch.zeros((world * B, cap, 60), dtype=torch.uint8, device=dev)  # rank-major concatenation
+        g_n = torch.zeros(world * B, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def extract():

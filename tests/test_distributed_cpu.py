@@ -1,0 +1,90 @@
+"""Multi-rank path on CPU (gloo, world size 2): frame sharding, the per-step padded gather and the
+max-over-ranks timing reduction that bench.py uses -- no GPU, no data-path collective besides the gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "orb_slam3_v1.0_amd", "python"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, frames_total, out_q):
+    import oracle_py as O
+    from orbfe import synth
+    from orbfe.shard import shard_range, pack_results, unpack_results
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = (120, 6000, 1.2, 3, 20, 7, 128, 96)
+    e = O.Extractor(*args)  # the oracle stands in for the GPU extractor: same output layout
+    lo, hi = shard_range(frames_total, rank, world)
+    B = (frames_total + world - 1) // world
+    cap = e.cap
+    kp = np.zeros((B, cap), O.KP_DTYPE)
+    desc = np.zeros((B, cap, 32), np.uint8)
+    n = np.zeros(B, np.int32)
+    for j, fidx in enumerate(range(lo, hi)):
+        k, d, _ = e.extract(synth.frame(128, 96, fidx))
+        n[j] = len(k)
+        kp[j, :len(k)] = k
+        desc[j, :len(k)] = d
+    pack = torch.from_numpy(pack_results(kp, desc, np.full((B, cap), -1, np.int32)))
+    g = torch.zeros((world * B,) + tuple(pack.shape[1:]), dtype=torch.uint8)  # concatenated along dim 0
+    dist.all_gather_into_tensor(g, pack)
+    g = g.view((world,) + tuple(pack.shape))
+    gn = torch.zeros(world * B, dtype=torch.int32)
+    dist.all_gather_into_tensor(gn, torch.from_numpy(n))
+    gn = gn.view(world, B)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        res = []
+        for r in range(world):
+            rlo, rhi = shard_range(frames_total, r, world)
+            k_all, d_all, _ = unpack_results(g[r].numpy(), O.KP_DTYPE)
+            for j in range(rhi - rlo):
+                c = int(gn[r, j])
+                res.append((rlo + j, k_all[j, :c].tobytes(), d_all[j, :c].tobytes()))
+        out_q.put((res, float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_gather_world2():
+    import oracle_py as O
+    from orbfe import synth
+    from orbfe.shard import shard_range
+    frames_total, world = 5, 2  # ragged: ranks own 3 and 2 frames
+    assert shard_range(5, 0, 2) == (0, 3) and shard_range(5, 1, 2) == (3, 5) and shard_range(1, 1, 2) == (1, 1)
+    O.lib()  # build the oracle once before forking workers
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, frames_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tmax == 2.0  # MAX over ranks
+    e = O.Extractor(120, 6000, 1.2, 3, 20, 7, 128, 96)
+    assert sorted(r[0] for r in res) == list(range(frames_total))
+    for fidx, kb, db in res:
+        k, d, _ = e.extract(synth.frame(128, 96, fidx))
+        assert kb == k.tobytes() and db == d.tobytes()
