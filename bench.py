@@ -54,6 +54,26 @@ def algorithmic_bytes_per_frame(ex, n_kp):
     return per_stage, 4 * P - int(px[0]) - int(px[-1]) + 1317 * int(n_kp)
 
 
+STAGE_KERNEL = {"pyramid_resize": "resize_kernel", "fast_nms_blur": "fast_blur_kernel", "quadtree": "quadtree_kernel",
+                "orient_brief": "orient_brief_kernel"}
+
+
+def pmc_traffic(stage, workload, batch):
+    """HBM bytes per launch of the stage's kernel from the committed PMC passes (profiles/r01_traffic_pmc.json:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 corrections applied by
+    tools/traffic_report.py).  Counters cannot be read from inside the timed process, so this is the number of the
+    last profiled run of the SAME workload / batch; null otherwise."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
+        meta = d.get("_meta", {})
+        if meta.get("workload") != workload or meta.get("frames_per_launch") != batch:
+            return None
+        tot = [v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if STAGE_KERNEL[stage] in k]
+        return float(tot[0]) if tot else None  # average over the profiled launches of that kernel
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def make_map_points(kp, n, desc, M, rng, n_levels, mp_dtype):
     """C3 recipe, vectorised: descriptor of a random keypoint with 0..20 bit flips, projection = that
     keypoint +- 3 px, level = its octave."""
@@ -253,7 +273,7 @@ def main():
                        "mean_matches_per_frame": float(d_nmatch.float().mean().item()) if M else None,
                        "gather": "rccl all_gather of kp+desc+match per step" if gather else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, a.workload, B),
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
                          "extract_pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
                          "stage_ms_per_step": stage_avg},
