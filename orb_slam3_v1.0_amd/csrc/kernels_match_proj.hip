@@ -68,6 +68,7 @@ struct ProjArgs {
     int* claimG;                  // [B][kpStride] fallback claim table (n > kLdsClaims)
     int* perm;                    // [B][M] map points ordered by pyramid level (work assignment of the top-K pass)
     int* dbg;                     // [B][4] diagnostics: sweeps, cooperative rescans, chunks, -
+    int* lvlStart;                // [B][34] first keypoint index per level (level-major input), [33] = sorted flag
     int* matchOut;                // [B][kpStride]
     int* nMatches;                // [B]
 };
@@ -189,6 +190,28 @@ __global__ __launch_bounds__(1024) void proj_sort_kernel(ProjArgs A)
         const int pos = atomicAdd(&sHist[sort_bucket(A, mps[i])], 1);
         A.perm[(size_t)f * A.M + pos] = i;
     }
+
+    // Keypoint index range per pyramid level.  The extractor emits keypoints level-major
+    // (src/ORBextractor.cc:499-500); when that holds, lvlStart[l] = first index with octave >= l and a
+    // block of the top-K pass only walks the levels its map points can match.  For any other order
+    // lvlStart[33] = 0 ("not sorted") and the pass walks everything.
+    __shared__ int sStart[34];
+    __syncthreads();
+    const int n = A.nKp[f];
+    const orbfe_keypoint* kp = A.kp + (size_t)f * A.kpStride;
+    if (tid < 33) sStart[tid] = n;
+    if (tid == 33) sStart[33] = 1;
+    __syncthreads();
+    for (int j = tid; j < n; j += 1024) {
+        const int o = min(max(kp[j].octave, 0), 32);
+        atomicMin(&sStart[o], j);
+        if (j + 1 < n && kp[j + 1].octave < kp[j].octave) sStart[33] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int l2 = 31; l2 >= 0; l2--) sStart[l2] = min(sStart[l2], sStart[l2 + 1]);
+        for (int l2 = 0; l2 < 34; l2++) A.lvlStart[f * 34 + l2] = sStart[l2];
+    }
 }
 
 // Thread per map point; a block owns 256 map points of one frame and stages the frame's keypoints
@@ -219,8 +242,26 @@ __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
 #pragma unroll
     for (int t = 0; t < kTopK; t++) keys[t] = kKeyNone;
     int total = 0;
-    for (int base = 0; base < n; base += kCandChunk) {
-        const int m = min(kCandChunk, n - base);
+    // keypoint index range this block has to look at: the levels [min(lvl)-1, max(lvl)] of its map points
+    __shared__ int sLvlLo, sLvlHi;
+    if (threadIdx.x == 0) { sLvlLo = 64; sLvlHi = -1; }
+    __syncthreads();
+    if (w.valid) {
+        atomicMin(&sLvlLo, w.minLevel);
+        atomicMax(&sLvlHi, w.maxLevel);
+    }
+    __syncthreads();
+    int jlo = 0, jhi = n;
+    {
+        const int* ls = A.lvlStart + f * 34;
+        if (sLvlHi < 0) jhi = 0;  // no valid map point in this block
+        else if (ls[33]) {        // level-major keypoints
+            jlo = ls[min(max(sLvlLo, 0), 32)];
+            jhi = ls[min(sLvlHi + 1, 32)];
+        }
+    }
+    for (int base = jlo; base < jhi; base += kCandChunk) {
+        const int m = min(kCandChunk, jhi - base);
         __syncthreads();
         for (int j = threadIdx.x; j < m; j += 256) {
             const orbfe_keypoint k = kp[base + j];
@@ -461,6 +502,7 @@ int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::st
     const size_t oClaim = sc.take((size_t)B * A.kpStride * sizeof(int));
     const size_t oPerm = sc.take((size_t)B * std::max(M, 1) * sizeof(int));
     const size_t oDbg = sc.take((size_t)B * 4 * sizeof(int));
+    const size_t oLvl = sc.take((size_t)B * 34 * sizeof(int));
     int rc = ensure(m, sc.off, hostNeed + 256, err);
     if (rc != ORBFE_OK) return rc;
     uint8_t* dp = static_cast<uint8_t*>(m.d);
@@ -470,6 +512,7 @@ int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::st
     A.claimG = reinterpret_cast<int*>(dp + oClaim);
     A.perm = reinterpret_cast<int*>(dp + oPerm);
     A.dbg = reinterpret_cast<int*>(dp + oDbg);
+    A.lvlStart = reinterpret_cast<int*>(dp + oLvl);
     return ORBFE_OK;
 }
 

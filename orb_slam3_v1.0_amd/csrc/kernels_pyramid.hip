@@ -11,12 +11,13 @@
 
 namespace orbfe {
 
-// Output tile 256 x 4 per 256-thread block; the source footprint (<= 8 rows x 520 px for scale
-// factors up to 2) is staged in LDS with dword loads, then every thread produces 4 pixels and
-// stores one dword.  xtab/ytab hold (x1 | Q11 weight << 16), 16-byte aligned per level.
-// Algorithmic bytes per output pixel: 1 written + scale^2 read.
-constexpr int kRsTW = 256, kRsTH = 4;
-constexpr int kRsMaxRows = 8, kRsMaxCols = 528;
+// Output tile 256 x 8 per 256-thread block.  The source footprint (<= 20 rows x 528 px, i.e. scale
+// factors up to ~2.2) is staged in LDS with dword loads whose addresses come from integer arithmetic
+// (no dependent table load in front of the staging); the weight tables are fetched meanwhile.
+// Every thread produces 2 x 4 pixels and stores two dwords.  xtab/ytab hold (x1 | Q11 weight << 16),
+// 16-byte aligned per level.  Algorithmic bytes per output pixel: 1 written + scale^2 read.
+constexpr int kRsTW = 256, kRsTH = 8;
+constexpr int kRsMaxRows = 20, kRsMaxCols = 528;
 
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, size_t srcFrameStride,
                                                      int sw, int sh, int spitch, int srcAligned4,
@@ -33,78 +34,89 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
     const int tid = threadIdx.x;
     const uint8_t* s = src + (size_t)f * srcFrameStride;
 
-    // source footprint of this tile (uniform)
+    // this thread's outputs: 4 pixels at x0 in rows y and y + 4; table entries requested up front
+    const int x0 = tx0 + (tid & 63) * 4;
+    const int yA = ty0 + (tid >> 6), yB = yA + 4;
+    const bool colOk = x0 < dw;
+    uint4 xt4 = make_uint4(0, 0, 0, 0);
+    uint32_t ytA = 0, ytB = 0;
+    if (colOk) xt4 = *reinterpret_cast<const uint4*>(xtab + x0);  // table padded to a multiple of 4
+    if (yA < dh) ytA = ytab[yA];
+    if (yB < dh) ytB = ytab[yB];
+
+    // source footprint of the tile from the same integer formula the tables were built with
     const int txLast = min(tx0 + kRsTW, dw) - 1;
     const int tyLast = min(ty0 + kRsTH, dh) - 1;
-    const int sx0 = (int)(xtab[tx0] & 0xffffu) & ~3;               // dword-aligned left edge
-    const int sx1 = min((int)(xtab[txLast] & 0xffffu) + 1, sw - 1);
-    const int sy0 = (int)(ytab[ty0] & 0xffffu);
-    const int sy1 = min((int)(ytab[tyLast] & 0xffffu) + 1, sh - 1);
+    const int sx0 = (int)(((long long)tx0 * sw) / dw) & ~3;                      // dword-aligned left edge
+    const int sx1 = min((int)(((long long)txLast * sw) / dw) + 1, sw - 1);
+    const int sy0 = (int)(((long long)ty0 * sh) / dh);
+    const int sy1 = min((int)(((long long)tyLast * sh) / dh) + 1, sh - 1);
     const int nrows = sy1 - sy0 + 1;
-    const int ndw = (sx1 - sx0) / 4 + 1;                            // dwords per staged row
+    const int ndw = (sx1 - sx0) / 4 + 1;                                          // dwords per staged row
     const bool staged = nrows <= kRsMaxRows && ndw * 4 <= kRsMaxCols;
 
     if (staged) {
-        for (int e = tid; e < nrows * ndw; e += 256) {
-            const int r = e / ndw;
-            const int c4 = e - r * ndw;
-            const int gx = sx0 + 4 * c4;
+        // thread (c4, r) grid over the footprint: 64 dword columns x 4 rows per pass, no division
+        const int c4l = tid & 63, rl = tid >> 6;
+        for (int r = rl; r < nrows; r += 4) {
             const uint8_t* row = s + (size_t)(sy0 + r) * spitch;
-            uint32_t wv;
-            if (srcAligned4 && gx + 3 < sw) {
-                wv = *reinterpret_cast<const uint32_t*>(row + gx);
-            } else {
-                wv = 0;
+            for (int c4 = c4l; c4 < ndw; c4 += 64) {
+                const int gx = sx0 + 4 * c4;
+                uint32_t wv;
+                if (srcAligned4 && gx + 3 < sw) {
+                    wv = *reinterpret_cast<const uint32_t*>(row + gx);
+                } else {
+                    wv = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (gx + i < sw) wv |= (uint32_t)row[gx + i] << (8 * i);
+                    for (int i = 0; i < 4; i++)
+                        if (gx + i < sw) wv |= (uint32_t)row[gx + i] << (8 * i);
+                }
+                *reinterpret_cast<uint32_t*>(&sSrc[r][4 * c4]) = wv;
             }
-            *reinterpret_cast<uint32_t*>(&sSrc[r][4 * c4]) = wv;
         }
         __syncthreads();
     }
+    if (!colOk) return;
 
-    const int x0 = tx0 + (tid & 63) * 4;
-    const int y = ty0 + (tid >> 6);
-    if (x0 >= dw || y >= dh) return;
-    uint8_t* d = dst + (size_t)f * dstFrameStride + (size_t)y * dpitch;
-
-    const uint32_t yt = ytab[y];
-    const int y1 = (int)(yt & 0xffffu);
-    const uint32_t wy = yt >> 16;
-    const int y2 = min(y1 + 1, sh - 1);
-    const uint4 xt4 = *reinterpret_cast<const uint4*>(xtab + x0);  // table padded to a multiple of 4
     const uint32_t xt[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
-
-    uint32_t outw = 0;
     const int nvalid = min(4, dw - x0);
+    // two separately compiled bodies: the LDS one must index sSrc directly (a pointer merged with the
+    // global fallback would degrade every LDS read to a flat load)
+    auto body = [&](auto fetch) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i < nvalid) {
-            const int x1 = (int)(xt[i] & 0xffffu);
-            const uint32_t wx = xt[i] >> 16;
-            const int x2 = min(x1 + 1, sw - 1);
-            uint32_t a, b, c, e;
-            if (staged) {
-                const uint8_t* r1 = sSrc[y1 - sy0];
-                const uint8_t* r2 = sSrc[y2 - sy0];
-                a = r1[x1 - sx0]; b = r1[x2 - sx0]; c = r2[x1 - sx0]; e = r2[x2 - sx0];
-            } else {
-                const uint8_t* r1 = s + (size_t)y1 * spitch;
-                const uint8_t* r2 = s + (size_t)y2 * spitch;
-                a = r1[x1]; b = r1[x2]; c = r2[x1]; e = r2[x2];
+        for (int half = 0; half < 2; half++) {
+            const int y = half ? yB : yA;
+            if (y >= dh) continue;
+            const uint32_t yt = half ? ytB : ytA;
+            const int y1 = (int)(yt & 0xffffu);
+            const uint32_t wy = yt >> 16;
+            const int y2 = min(y1 + 1, sh - 1);
+            uint32_t outw = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i < nvalid) {
+                    const int x1 = (int)(xt[i] & 0xffffu);
+                    const uint32_t wx = xt[i] >> 16;
+                    const int x2 = min(x1 + 1, sw - 1);
+                    const uint32_t a = fetch(y1, x1), b = fetch(y1, x2), c = fetch(y2, x1), e = fetch(y2, x2);
+                    const uint32_t top = a * (2048u - wx) + b * wx;
+                    const uint32_t bot = c * (2048u - wx) + e * wx;
+                    const uint32_t v = top * (2048u - wy) + bot * wy;
+                    outw |= ((v + (1u << 21)) >> 22) << (8 * i);
+                }
             }
-            const uint32_t top = a * (2048u - wx) + b * wx;
-            const uint32_t bot = c * (2048u - wx) + e * wx;
-            const uint32_t v = top * (2048u - wy) + bot * wy;
-            outw |= ((v + (1u << 21)) >> 22) << (8 * i);
+            uint8_t* d = dst + (size_t)f * dstFrameStride + (size_t)y * dpitch;
+            if (nvalid == 4) {
+                *reinterpret_cast<uint32_t*>(d + x0) = outw;  // dpitch % 64 == 0 and x0 % 4 == 0
+            } else {
+                for (int i = 0; i < nvalid; i++) d[x0 + i] = (uint8_t)(outw >> (8 * i));
+            }
         }
-    }
-    if (nvalid == 4) {
-        *reinterpret_cast<uint32_t*>(d + x0) = outw;  // dpitch % 64 == 0 and x0 % 4 == 0
-    } else {
-        for (int i = 0; i < nvalid; i++) d[x0 + i] = (uint8_t)(outw >> (8 * i));
-    }
+    };
+    if (staged)
+        body([&](int yy, int xx) -> uint32_t { return sSrc[yy - sy0][xx - sx0]; });
+    else
+        body([&](int yy, int xx) -> uint32_t { return s[(size_t)yy * spitch + xx]; });
 }
 
 void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFrameStride, int sw, int sh,

@@ -308,10 +308,12 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
 
     for (int round = 0; round < kQtMaxRounds; round++) {
         const int prevSize = n;
-        Box* box = sBox[cur];
-        int* ncnt = sCnt[cur];
-        Box* nbox = sBox[cur ^ 1];
-        int* nncnt = sCnt[cur ^ 1];
+        // constant indices + select (not sBox[cur]): keeps the pointer arrays in registers so the
+        // compiler can still prove the LDS address space (otherwise every access becomes a flat op)
+        Box* box = cur ? sBox[1] : sBox[0];
+        int* ncnt = cur ? sCnt[1] : sCnt[0];
+        Box* nbox = cur ? sBox[0] : sBox[1];
+        int* nncnt = cur ? sCnt[0] : sCnt[1];
 
         // 1. child counts
         for (int i = tid; i < n * 4; i += kQtThreads) sCC[i] = 0;
