@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only")
+    ap.add_argument("--no-overlap", action="store_true", help="match on the extraction stream (no 2-stream pipelining)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,30 +165,36 @@ def main():
     # ---- synthetic stream, resident in HBM before the timed region ----
     frames = np.stack(list(synth.stream(W, H, B, index0=rank)))
     d_gray = torch.from_numpy(frames).to(dev)
-    d_kp = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_per = torch.zeros((B, ex.nlevels), dtype=torch.int32, device=dev)
-    d_match = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
-    d_nmatch = torch.zeros(B, dtype=torch.int32, device=dev)
+    # double-buffered outputs: extraction of step i+1 (stream s1) overlaps the matching of step i (stream s2)
+    nbuf = 2 if (M and not a.no_overlap) else 1
+    bufs = []
+    for _ in range(nbuf):
+        bufs.append(dict(kp=torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev),
+                         desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+                         n=torch.zeros(B, dtype=torch.int32, device=dev),
+                         per=torch.zeros((B, ex.nlevels), dtype=torch.int32, device=dev),
+                         match=torch.full((B, cap), -1, dtype=torch.int32, device=dev),
+                         nmatch=torch.zeros(B, dtype=torch.int32, device=dev),
+                         ev_ext=torch.cuda.Event(), ev_done=torch.cuda.Event()))
     gather = world > 1 and not a.no_gather
     if gather:
         pack = torch.zeros((B, cap, 60), dtype=torch.uint8, device=dev)  # kp 24 + desc 32 + match 4
         g_out = torch.zeros((world * B, cap, 60), dtype=torch.uint8, device=dev)  # rank-major concatenation
         g_n = torch.zeros(world * B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    s1 = torch.cuda.current_stream(dev)
+    s2 = torch.cuda.Stream(dev) if nbuf == 2 else s1
 
-    def extract():
-        ex.extract_batch_device(d_gray.data_ptr(), W * H, W, B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(),
-                                d_per.data_ptr(), stream.cuda_stream)
+    def extract(b):
+        ex.extract_batch_device(d_gray.data_ptr(), W * H, W, B, b["kp"].data_ptr(), b["desc"].data_ptr(),
+                                b["n"].data_ptr(), b["per"].data_ptr(), s1.cuda_stream)
 
     # ---- map points (C3 recipe) from one untimed extraction; resident in HBM as well ----
-    extract()
+    extract(bufs[0])
     torch.cuda.synchronize(dev)
     if M:
-        kp_h = d_kp.cpu().numpy().reshape(B, cap * 24).view(orbfe.KP_DTYPE).reshape(B, cap)
-        desc_h = d_desc.cpu().numpy()
-        n_h = d_n.cpu().numpy()
+        kp_h = bufs[0]["kp"].cpu().numpy().reshape(B, cap * 24).view(orbfe.KP_DTYPE).reshape(B, cap)
+        desc_h = bufs[0]["desc"].cpu().numpy()
+        n_h = bufs[0]["n"].cpu().numpy()
         rng = np.random.default_rng(1234 + rank)
         mps_all = np.zeros((B, M), orbfe.MP_DTYPE)
         mpd_all = np.zeros((B, M, 32), np.uint8)
@@ -197,24 +204,35 @@ def main():
         d_mpd = torch.from_numpy(mpd_all.reshape(-1)).to(dev)
     ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    counter = [0]
 
     def step(i=None):
-        extract()
+        b = bufs[counter[0] % nbuf]
+        counter[0] += 1
+        if nbuf == 2:
+            s1.wait_event(b["ev_done"])  # this buffer's previous match (two steps ago) must have finished
+        extract(b)
+        if nbuf == 2:
+            b["ev_ext"].record(s1)
+            s2.wait_event(b["ev_ext"])
         if M:
             if i is not None:
-                ev_m0[i].record(stream)
-            matcher.SearchByProjection_batch_device(B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, GRID[0],
-                                                    GRID[1], 0.0, 0.0, float(W), float(H), M, d_mps.data_ptr(),
-                                                    d_mpd.data_ptr(), None, MATCH_TH, MATCH_NN, d_match.data_ptr(),
-                                                    d_nmatch.data_ptr(), stream=stream.cuda_stream)
+                ev_m0[i].record(s2)
+            matcher.SearchByProjection_batch_device(B, b["kp"].data_ptr(), b["desc"].data_ptr(), b["n"].data_ptr(), cap,
+                                                    GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), M, d_mps.data_ptr(),
+                                                    d_mpd.data_ptr(), None, MATCH_TH, MATCH_NN, b["match"].data_ptr(),
+                                                    b["nmatch"].data_ptr(), stream=s2.cuda_stream)
             if i is not None:
-                ev_m1[i].record(stream)
+                ev_m1[i].record(s2)
         if gather:
-            pack[:, :, :24] = d_kp
-            pack[:, :, 24:56] = d_desc
-            pack[:, :, 56:] = d_match.view(torch.uint8).reshape(B, cap, 4)
-            dist.all_gather_into_tensor(g_out, pack)
-            dist.all_gather_into_tensor(g_n, d_n)
+            with torch.cuda.stream(s2):
+                pack[:, :, :24] = b["kp"]
+                pack[:, :, 24:56] = b["desc"]
+                pack[:, :, 56:] = b["match"].view(torch.uint8).reshape(B, cap, 4)
+                dist.all_gather_into_tensor(g_out, pack)
+                dist.all_gather_into_tensor(g_n, b["n"])
+        if nbuf == 2:
+            b["ev_done"].record(s2)
 
     def barrier():
         if dist is not None:
@@ -239,7 +257,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    n_kp_mean = float(d_n.float().mean().item())
+    n_kp_mean = float(bufs[0]["n"].float().mean().item())
     if rank == 0:
         per_stage_bytes, b_frame = algorithmic_bytes_per_frame(ex, n_kp_mean)
         stage_avg = {k: v / max(1, ncalls) for k, v in stage_ms.items()}
@@ -270,8 +288,9 @@ def main():
                                    "scale=%.1f FAST %d/%d nFast=%d" % (a.workload, what, B, cfg[0], cfg[3], cfg[2], cfg[4],
                                                                          cfg[5], cfg[1]),
                        "frames_per_step": B * world, "mean_keypoints_per_frame": n_kp_mean,
-                       "mean_matches_per_frame": float(d_nmatch.float().mean().item()) if M else None,
-                       "gather": "rccl all_gather of kp+desc+match per step" if gather else "none"},
+                       "mean_matches_per_frame": float(bufs[0]["nmatch"].float().mean().item()) if M else None,
+                       "gather": "rccl all_gather of kp+desc+match per step" if gather else "none",
+                       "streams": "extract(step i+1) || match(step i), double-buffered outputs" if nbuf == 2 else "single stream"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, a.workload, B),
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
