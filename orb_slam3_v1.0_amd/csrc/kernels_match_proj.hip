@@ -41,7 +41,7 @@ namespace {
 constexpr int kClaimFree = 0x7fffffff;
 constexpr int kResolveThreads = 1024;
 constexpr int kTopK = 16;         // stored candidates per map point
-constexpr int kCandChunk = 1024;  // keypoints staged in LDS per pass (48 B each)
+constexpr int kCandChunk = 512;   // keypoints staged in LDS per pass (48 B each -> 24 KB, 6 blocks per CU)
 
 struct GridDesc {
     int cols, rows;
@@ -330,7 +330,16 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
         unsigned long long d4[4];
         const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * A.M + i) * 32);
         d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
-        for (int idx = lane; idx < n; idx += 64) {
+        // level-major keypoints: only the index range of levels [minLevel, maxLevel] can pass the filter
+        int jlo = 0, jhi = n;
+        {
+            const int* ls = A.lvlStart + f * 34;
+            if (ls[33]) {
+                jlo = ls[min(max(w.minLevel, 0), 32)];
+                jhi = ls[min(max(w.maxLevel, -1) + 1, 32)];
+            }
+        }
+        for (int idx = jlo + lane; idx < jhi; idx += 64) {
             if (claim[idx] < i) continue;
             int cell, oct, dist;
             float kx, ky;
