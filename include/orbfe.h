@@ -187,8 +187,9 @@ int orbfe_match_projection(orbfe_handle *h, const orbfe_frame_view *frame, int n
  * frame b's keypoints / descriptors / counts are the outputs of orbfe_extract_batch_device
  * (stride kp_stride == orbfe_max_keypoints()), its map points are d_map_points[b*n_map_points ..],
  * scale factors are the handle's own mvScaleFactor.  All d_* pointers are device pointers;
- * d_init_obs may be NULL.  Work is queued on `stream`; the call synchronises the stream once per
- * pair of fixed-point iterations to test convergence, so it returns with the results complete. */
+ * d_init_obs may be NULL.  Fully asynchronous on `stream` (a hipStream_t; NULL == the handle's own
+ * stream): three kernels are queued and no host synchronisation takes place; results are complete when
+ * the stream reaches that point. */
 int orbfe_match_projection_batch_device(orbfe_handle *h, int batch, const orbfe_keypoint *d_kp,
                                         const uint8_t *d_desc, const int *d_n, int kp_stride,
                                         int grid_cols, int grid_rows, float min_x, float min_y,

@@ -18,8 +18,9 @@
 //    each chunk iterated to its own fixed point while all earlier chunks are already final.
 //  * Only the K smallest keys of a map point are kept (sorted).  A sweep takes the first two that
 //    are still free; every candidate that was not stored is larger than all stored ones, so this is
-//    exact whenever two free entries are found or the list was not truncated.  Otherwise the map
-//    point falls back to an exact scan over all keypoints of the frame.
+//    exact whenever two free entries are found or the list was not truncated.  When the list runs dry
+//    the verdict is often already implied by the last stored distance; otherwise the map point is
+//    rescanned exactly (one wave, LDS-resident frame, only the index range of its two levels).
 //
 // Pipeline per call (B frames), all asynchronous on one stream, no host round trip:
 //   prep (grid cell per keypoint) -> top-K candidate keys per map point (thread per map point,
@@ -549,7 +550,6 @@ int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
 void match_scratch_free(MatchScratch& m)
 {
     if (m.d) (void)hipFree(m.d);
-    if (m.cand) (void)hipFree(m.cand);
     if (m.hpin) (void)hipHostFree(m.hpin);
     m = MatchScratch();
 }

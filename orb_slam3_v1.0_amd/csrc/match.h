@@ -12,8 +12,6 @@ struct MatchScratch {
     size_t dBytes = 0;
     void* hpin = nullptr;   // pinned host arena
     size_t hBytes = 0;
-    void* cand = nullptr;   // candidate-key arena of the projection matcher
-    size_t candBytes = 0;
 };
 
 void match_scratch_free(MatchScratch& m);

@@ -1,0 +1,48 @@
+"""The oracle under AddressSanitizer + UBSan (CPU build only; GPU ASan is not available on the pool).
+The reference reads out of bounds for keypoints near the border; the oracle's S3 border
+rule must keep every access inside the level images, also on tiny levels and with active caps."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DRIVER = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, "%(root)s/tests"); sys.path.insert(0, "%(root)s/orb_slam3_v1.0_amd/python")
+import oracle_py as O
+from orbfe import synth
+path = O.build(asan=True)
+L = C.CDLL(path)
+for cfg, idx in (((200, 8000, 1.2, 4, 20, 7, 160, 120), 3), ((60, 150, 1.2, 1, 20, 7, 96, 96), 4), ((100, 4000, 1.5, 4, 20, 7, 90, 70), 5)):
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_extract.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3
+    L.orc_max_keypoints.argtypes = [C.c_void_p]
+    L.orc_destroy.argtypes = [C.c_void_p]
+    h = L.orc_create(*cfg)
+    assert h
+    cap = L.orc_max_keypoints(h)
+    img = synth.frame(cfg[6], cfg[7], idx)
+    kp = np.zeros(cap * 24, np.uint8); desc = np.zeros(cap * 32, np.uint8); per = np.zeros(cfg[3], np.int32)
+    n = L.orc_extract(h, img.ctypes.data, img.strides[0], kp.ctypes.data, desc.ctypes.data, per.ctypes.data)
+    assert n > 0
+    L.orc_destroy(h)
+print("asan-ok")
+'''
+
+
+def test_oracle_clean_under_asan_ubsan(tmp_path):
+    try:
+        libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("gcc not available")
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not installed")
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    script = tmp_path / "drv.py"
+    script.write_text(DRIVER % {"root": ROOT})
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "asan-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
