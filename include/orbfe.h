@@ -212,6 +212,15 @@ int orbfe_match_bow(orbfe_handle *h, int n_groups, const int *kf_off, const int 
                     const uint8_t *f_desc, const float *f_angle, float nn_ratio,
                     int check_orientation, int *match_out, int *n_matches);
 
+/* replaces ORBmatcher::SearchForInitialization(F1, F2, windowSize, nnRatio, checkOrientation)
+ * (src/ORBmatcher.cc:329-439; caller src/Tracking.cc:605-607), mono.  HOST pointers.  Frame 1
+ * contributes keypoints + descriptors; frame 2 additionally its grid (GetFeaturesInArea runs on
+ * frame 2).  Only level-0 keypoints of frame 1 take part (:346-347).  matches12_out (f1->n ints)
+ * receives vnMatches12 (index in frame 2 or -1), *n_matches the function's return value. */
+int orbfe_match_initialization(orbfe_handle *h, const orbfe_frame_view *f1, const orbfe_frame_view *f2,
+                               int window_size, float nn_ratio, int check_orientation,
+                               int *matches12_out, int *n_matches);
+
 /* -------------------------------------------------------------------------------------------
  * Misc
  * ---------------------------------------------------------------------------------------- */

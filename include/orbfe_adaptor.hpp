@@ -188,6 +188,27 @@ public:
         return nmatches;
     }
 
+    // src/ORBmatcher.cc:329-439 (include/ORBmatcher.h:58): returns {nmatches, vnMatches12}
+    template <class FramePtr, class DescOfFrame>
+    static std::pair<int, std::vector<int>> SearchForInitialization(orbfe_handle* h, FramePtr F1, FramePtr F2, int windowSize,
+                                                                    const float nnRatio, const bool checkOrientation,
+                                                                    DescOfFrame frameDesc)
+    {
+        auto view = [&](const FramePtr& F) {
+            return orbfe_frame_view{(int)F->mvKeysUn->size(), reinterpret_cast<const orbfe_keypoint*>(F->mvKeysUn->data()),
+                                    frameDesc(F), F->getFrameGridCols(), F->getFrameGridRows(), F->mnMinX, F->mnMinY,
+                                    F->mfGridElementWidthInv, F->mfGridElementHeightInv, (int)F->mvScaleFactors.size(),
+                                    F->mvScaleFactors.data()};
+        };
+        const orbfe_frame_view v1 = view(F1), v2 = view(F2);
+        std::vector<int> m12(v1.n > 0 ? v1.n : 1, -1);
+        int nmatches = 0;
+        orbfe_detail::check(orbfe_match_initialization(h, &v1, &v2, windowSize, nnRatio, checkOrientation, m12.data(), &nmatches),
+                            h, "orbfe_match_initialization");
+        m12.resize(v1.n);
+        return {nmatches, m12};
+    }
+
     // src/ORBmatcher.cc:133-327.  FeatureVector = std::map<NodeId, std::vector<unsigned>> (DBoW2).  The merge-walk
     // over the two maps (:161-163,289-301) happens here on the host and is handed over as CSR groups.
     template <class KeyFramePtr, class FramePtr, class MapPointPtr, class FeatureVector, class DescOfKF, class DescOfFrame>

@@ -265,3 +265,89 @@ int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff
     for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
     return nmatches;
 }
+
+/* ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:329-439 (caller src/Tracking.cc:605-607).
+ * F1 contributes keypoints + descriptors, F2 additionally its grid (GetFeaturesInArea on F2, :349).
+ * matches12Out[i1] = index in F2 or -1 (vnMatches12); returns nmatches. */
+int orc_search_for_initialization(const orc_frame_view *F1, const orc_frame_view *F2, int windowSize,
+                                  float nnRatio, int checkOrientation, int *matches12Out)
+{
+    int nmatches = 0;
+    const int n1 = F1->n, n2 = F2->n;
+    for (int i = 0; i < n1; i++) matches12Out[i] = -1;
+    int *rotHist[HISTO_LENGTH];
+    int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
+        rotN[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    int *vMatchedDistance = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    int *vnMatches21 = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    int *vIndices2 = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    for (int i = 0; i < n2; i++) {
+        vMatchedDistance[i] = 0x7fffffff;
+        vnMatches21[i] = -1;
+    }
+    cell_t *g = build_grid(F2);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const orc_keypoint *kp1 = &F1->kp[i1];
+        const int level1 = kp1->octave;
+        if (level1 > 0) continue;                                                    /* :346-347 */
+        const int nI = features_in_area(F2, g, kp1->x, kp1->y, (float)windowSize, level1, level1, vIndices2);
+        if (nI == 0) continue;
+        const uint8_t *d1 = F1->desc + (size_t)i1 * 32;
+        int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+        for (int k = 0; k < nI; k++) {
+            const int i2 = vIndices2[k];
+            const int dist = orc_hamming(d1, F2->desc + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;                              /* :368-369 */
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_LOW) {                                                    /* :383 */
+            if ((float)bestDist < (float)bestDist2 * nnRatio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    matches12Out[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                matches12Out[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOrientation) {
+                    float rot = F1->kp[i1].angle - F2->kp[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin][rotN[bin]++] = i1;
+                }
+            }
+        }
+    }
+    if (checkOrientation) {                                                          /* :411-435 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) {
+                const int idx1 = rotHist[i][j];
+                if (matches12Out[idx1] >= 0) {
+                    matches12Out[idx1] = -1;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(vMatchedDistance);
+    free(vnMatches21);
+    free(vIndices2);
+    free_grid(F2, g);
+    return nmatches;
+}

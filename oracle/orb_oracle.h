@@ -120,6 +120,11 @@ int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff
                       int nF, const uint8_t *fDesc, const float *fAngle, float nnRatio,
                       int checkOrientation, int *matchOut);
 
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:329-439), mono.  Only level-0 keypoints of
+ * F1 take part; candidates come from F2's grid.  matches12Out[i1] (F1->n ints) = index in F2 or -1. */
+int orc_search_for_initialization(const orc_frame_view *F1, const orc_frame_view *F2, int windowSize,
+                                  float nnRatio, int checkOrientation, int *matches12Out);
+
 /* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480): linear cell per kp or -1 */
 void orc_assign_grid(const orc_frame_view *F, int *cellOut);
 

@@ -1,0 +1,290 @@
+// kernels_match_init.hip -- ORBmatcher::SearchForInitialization on gfx950.
+//
+// Replaces src/ORBmatcher.cc:329-439 (caller src/Tracking.cc:605-607): for every LEVEL-0 keypoint of
+// frame 1, in index order, the best / second-best Hamming match among the level-0 keypoints of
+// frame 2 inside a square window (Frame::GetFeaturesInArea on frame 2's grid), where a candidate
+// is skipped if it already holds a match at a distance <= ours (vMatchedDistance, :368-369) and an
+// accepted match STEALS the keypoint from its previous owner (:387-391); then the rotation
+// histogram filter (:411-435), whose bin counts include matches that were stolen later.
+//
+// The running per-target minimum makes every step depend on all earlier ones, and the function
+// runs once per frame pair during map initialisation on <= N_0 + 3 keypoints, so the exact design
+// is the simple one: ONE block walks frame 1's level-0 keypoints sequentially; for each of them
+// all threads scan frame 2 (staged in LDS: cell, octave, position, descriptor), reduce the two
+// smallest keys under the total order (distance, visit position) and thread 0 applies the update.
+#include <cstring>
+
+#include "match_common.h"
+
+#pragma clang fp contract(off)
+
+namespace orbfe {
+
+namespace {
+
+constexpr int kInitThreads = 1024;
+constexpr int kInitN = 2048;  // frame-2 keypoints that fit the LDS image
+constexpr int kIntMax = 0x7fffffff;
+
+struct InitArgs {
+    int n1, n2;
+    const orbfe_keypoint* kp1;
+    const uint8_t* desc1;
+    const orbfe_keypoint* kp2;
+    const uint8_t* desc2;
+    int cols, rows;
+    float minX, minY, invW, invH;
+    float r;  // windowSize
+    float nnRatio;
+    int checkOrientation;
+    int* matches12;   // [n1]
+    int* nMatches;    // [1]
+    int* matched21;   // [n2] scratch: vnMatches21
+    int* matchedDist; // [n2] scratch: vMatchedDistance
+    int* cell2;       // [n2] scratch
+    int* list0;       // [n1] scratch: level-0 keypoints of frame 1 in index order
+    int* binOf;       // [n1] scratch: rotation bin pushed for i1, or -1
+};
+
+struct InitLds {
+    int4 kp[kInitN];  // {cell, octave, x bits, y bits}
+    unsigned long long desc[kInitN][4];
+    int dist[kInitN];  // vMatchedDistance
+};
+
+template <bool LDS>
+__global__ __launch_bounds__(kInitThreads) void init_match_kernel(InitArgs A)
+{
+    __shared__ InitLds S;
+    __shared__ unsigned long long sK1[kInitThreads / 64], sK2[kInitThreads / 64];
+    __shared__ int sHist[ORBFE_HISTO_LENGTH];
+    __shared__ int sWave[kInitThreads / 64];
+    __shared__ int sN0, sNm, sInd[3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n1 = A.n1, n2 = A.n2;
+
+    // ---- frame 2: grid cell per keypoint (Frame::PosInGrid, src/Frame.cc:470-480) + state ----
+    for (int j = tid; j < n2; j += kInitThreads) {
+        const orbfe_keypoint k = A.kp2[j];
+        float px = k.x - A.minX; px = px * A.invW;
+        float py = k.y - A.minY; py = py * A.invH;
+        const int posX = (int)roundf(px), posY = (int)roundf(py);
+        const int lin = posY * A.cols + posX;
+        const int cell = (lin >= 0 && lin < A.cols * A.rows) ? ((lin % A.cols) | ((lin / A.cols) << 16)) : -1;
+        A.cell2[j] = cell;
+        A.matched21[j] = -1;
+        if (LDS) {
+            S.kp[j] = make_int4(cell, k.octave, __float_as_int(k.x), __float_as_int(k.y));
+            S.dist[j] = kIntMax;
+        } else {
+            A.matchedDist[j] = kIntMax;
+        }
+    }
+    if (LDS) {
+        const unsigned long long* d2 = reinterpret_cast<const unsigned long long*>(A.desc2);
+        for (int j = tid; j < n2 * 4; j += kInitThreads) S.desc[0][j] = d2[j];
+    }
+    if (tid < ORBFE_HISTO_LENGTH) sHist[tid] = 0;
+    if (tid == 0) { sN0 = 0; sNm = 0; }
+    __syncthreads();
+
+    // ---- frame 1: ordered list of level-0 keypoints (level1 > 0 -> continue, :346-347) ----
+    for (int base = 0; base < n1; base += kInitThreads) {
+        const int i = base + tid;
+        const int flag = (i < n1 && A.kp1[i].octave <= 0) ? 1 : 0;
+        if (i < n1) { A.matches12[i] = -1; A.binOf[i] = -1; }
+        int incl = flag;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) sWave[wv] = incl;
+        __syncthreads();
+        int pos = sN0 + incl - flag;
+        for (int q = 0; q < wv; q++) pos += sWave[q];
+        if (flag) A.list0[pos] = i;
+        __syncthreads();
+        if (tid == kInitThreads - 1) sN0 = pos + flag;
+        __syncthreads();
+    }
+    const int n0 = sN0;
+    int* mdist = LDS ? S.dist : A.matchedDist;
+    const float factor = 1.0f / ORBFE_HISTO_LENGTH;
+
+    for (int t = 0; t < n0; t++) {
+        const int i1 = A.list0[t];
+        const orbfe_keypoint k1p = A.kp1[i1];
+        // GetFeaturesInArea(x, y, windowSize, level1, level1) on frame 2, src/Frame.cc:413-435
+        const float x = k1p.x, y = k1p.y, r = A.r;
+        float tt;
+        tt = x - A.minX; tt = tt - r; tt = tt * A.invW;
+        const int minCX = max(0, (int)floorf(tt));
+        tt = x - A.minX; tt = tt + r; tt = tt * A.invW;
+        const int maxCX = min(A.cols - 1, (int)ceilf(tt));
+        tt = y - A.minY; tt = tt - r; tt = tt * A.invH;
+        const int minCY = max(0, (int)floorf(tt));
+        tt = y - A.minY; tt = tt + r; tt = tt * A.invH;
+        const int maxCY = min(A.rows - 1, (int)ceilf(tt));
+        const bool any = !(minCX >= A.cols || maxCX < 0 || minCY >= A.rows || maxCY < 0);
+        const int level1 = k1p.octave;
+        unsigned long long k1 = kKeyNone, k2 = kKeyNone;
+        if (any) {
+            unsigned long long d4[4];
+            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.desc1 + (size_t)i1 * 32);
+            d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
+            for (int j = tid; j < n2; j += kInitThreads) {
+                int cell, oct;
+                float kx, ky;
+                if (LDS) {
+                    const int4 q = S.kp[j];
+                    cell = q.x; oct = q.y; kx = __int_as_float(q.z); ky = __int_as_float(q.w);
+                } else {
+                    cell = A.cell2[j];
+                    const orbfe_keypoint k = A.kp2[j];
+                    oct = k.octave; kx = k.x; ky = k.y;
+                }
+                if (cell < 0) continue;
+                const int cx = cell & 0xffff, cy = cell >> 16;
+                if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;
+                // bCheckLevels = (minLevel > 0) || (maxLevel >= 0) with minLevel = maxLevel = level1
+                const bool checkLevels = (level1 > 0) || (level1 >= 0);
+                if (checkLevels && (oct < level1 || (level1 >= 0 && oct > level1))) continue;
+                const float dx = kx - x, dy = ky - y;
+                if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+                int dist;
+                if (LDS)
+                    dist = __popcll(S.desc[j][0] ^ d4[0]) + __popcll(S.desc[j][1] ^ d4[1]) + __popcll(S.desc[j][2] ^ d4[2]) +
+                           __popcll(S.desc[j][3] ^ d4[3]);
+                else
+                    dist = hamming256(reinterpret_cast<const uint2*>(A.desc2 + (size_t)j * 32), d4);
+                if (mdist[j] <= dist) continue;  // :368-369
+                const unsigned long long key = ((unsigned long long)dist << 52) | ((unsigned long long)cx << 36) |
+                                               ((unsigned long long)cy << 20) | (unsigned long long)j;
+                if (key < k1) { k2 = k1; k1 = key; }
+                else if (key < k2) k2 = key;
+            }
+        }
+        wave_top2(k1, k2);
+        if (lane == 0) { sK1[wv] = k1; sK2[wv] = k2; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b1 = kKeyNone, b2 = kKeyNone;
+            for (int q = 0; q < kInitThreads / 64; q++) top2_merge(b1, b2, sK1[q], sK2[q]);
+            if (b1 != kKeyNone) {
+                const int bestDist = (int)(b1 >> 52), bestIdx2 = (int)(b1 & 0xFFFFF);
+                const int bestDist2 = b2 == kKeyNone ? kIntMax : (int)(b2 >> 52);
+                if (bestDist <= ORBFE_TH_LOW && (float)bestDist < (float)bestDist2 * A.nnRatio) {  // :383-385
+                    const int prev = A.matched21[bestIdx2];
+                    if (prev >= 0) { A.matches12[prev] = -1; sNm--; }
+                    A.matches12[i1] = bestIdx2;
+                    A.matched21[bestIdx2] = i1;
+                    mdist[bestIdx2] = bestDist;
+                    sNm++;
+                    if (A.checkOrientation) {
+                        float rot = k1p.angle - A.kp2[bestIdx2].angle;
+                        if (rot < 0.0) rot = rot + 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+                        sHist[bin]++;
+                        A.binOf[i1] = bin;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- rotation histogram filter (:411-435; ComputeThreeMaxima :1328-1370) ----
+    if (A.checkOrientation) {
+        if (tid == 0) {
+            int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < ORBFE_HISTO_LENGTH; i++) {
+                const int s = sHist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+            sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += kInitThreads) {
+            const int b = A.binOf[i];
+            if (b >= 0 && b != sInd[0] && b != sInd[1] && b != sInd[2] && A.matches12[i] >= 0) {
+                A.matches12[i] = -1;
+                atomicSub(&sNm, 1);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *A.nMatches = sNm;
+}
+
+}  // namespace
+
+int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* F1, const orbfe_frame_view* F2,
+                             int windowSize, float nnRatio, int checkOrientation, int* matches12Out, int* nMatches,
+                             std::string& err)
+{
+    const int n1 = F1->n, n2 = F2->n;
+    for (int i = 0; i < n1; i++) matches12Out[i] = -1;
+    *nMatches = 0;
+    if (n1 == 0 || n2 == 0) return ORBFE_OK;
+    if (n2 >= (1 << 20) || F2->grid_cols > 65535 || F2->grid_rows > 32767) return ORBFE_ERR_UNSUPPORTED;
+    Carver c;
+    const size_t oKp1 = c.take((size_t)n1 * sizeof(orbfe_keypoint));
+    const size_t oD1 = c.take((size_t)n1 * 32);
+    const size_t oKp2 = c.take((size_t)n2 * sizeof(orbfe_keypoint));
+    const size_t oD2 = c.take((size_t)n2 * 32);
+    const size_t inBytes = c.off;
+    const size_t oM12 = c.take((size_t)n1 * sizeof(int));
+    const size_t oNM = c.take(sizeof(int));
+    const size_t outBytes = c.off - oM12;
+    const size_t oM21 = c.take((size_t)n2 * sizeof(int));
+    const size_t oMD = c.take((size_t)n2 * sizeof(int));
+    const size_t oCell = c.take((size_t)n2 * sizeof(int));
+    const size_t oL0 = c.take((size_t)n1 * sizeof(int));
+    const size_t oBin = c.take((size_t)n1 * sizeof(int));
+    int rc = ensure(m, c.off, inBytes + outBytes + 256, err);
+    if (rc != ORBFE_OK) return rc;
+    uint8_t* hp = static_cast<uint8_t*>(m.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(m.d);
+    memcpy(hp + oKp1, F1->kp, (size_t)n1 * sizeof(orbfe_keypoint));
+    memcpy(hp + oD1, F1->desc, (size_t)n1 * 32);
+    memcpy(hp + oKp2, F2->kp, (size_t)n2 * sizeof(orbfe_keypoint));
+    memcpy(hp + oD2, F2->desc, (size_t)n2 * 32);
+    MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
+    InitArgs A{};
+    A.n1 = n1; A.n2 = n2;
+    A.kp1 = reinterpret_cast<const orbfe_keypoint*>(dp + oKp1);
+    A.desc1 = dp + oD1;
+    A.kp2 = reinterpret_cast<const orbfe_keypoint*>(dp + oKp2);
+    A.desc2 = dp + oD2;
+    A.cols = F2->grid_cols; A.rows = F2->grid_rows;
+    A.minX = F2->min_x; A.minY = F2->min_y; A.invW = F2->grid_inv_w; A.invH = F2->grid_inv_h;
+    A.r = (float)windowSize;
+    A.nnRatio = nnRatio;
+    A.checkOrientation = checkOrientation;
+    A.matches12 = reinterpret_cast<int*>(dp + oM12);
+    A.nMatches = reinterpret_cast<int*>(dp + oNM);
+    A.matched21 = reinterpret_cast<int*>(dp + oM21);
+    A.matchedDist = reinterpret_cast<int*>(dp + oMD);
+    A.cell2 = reinterpret_cast<int*>(dp + oCell);
+    A.list0 = reinterpret_cast<int*>(dp + oL0);
+    A.binOf = reinterpret_cast<int*>(dp + oBin);
+    if (n2 <= kInitN)
+        hipLaunchKernelGGL(init_match_kernel<true>, dim3(1), dim3(kInitThreads), 0, s, A);
+    else
+        hipLaunchKernelGGL(init_match_kernel<false>, dim3(1), dim3(kInitThreads), 0, s, A);
+    MCHK(hipGetLastError());
+    uint8_t* hOut = hp + inBytes;
+    MCHK(hipMemcpyAsync(hOut, dp + oM12, outBytes, hipMemcpyDeviceToHost, s));
+    MCHK(hipStreamSynchronize(s));
+    memcpy(matches12Out, hOut, (size_t)n1 * sizeof(int));
+    *nMatches = *reinterpret_cast<int*>(hOut + (oNM - oM12));
+    return ORBFE_OK;
+}
+
+}  // namespace orbfe

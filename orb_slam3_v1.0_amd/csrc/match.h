@@ -28,6 +28,10 @@ int match_projection_batch_device(MatchScratch& m, hipStream_t s, int B, const o
                                   int farPoints, float thFar, float nnRatio, int* dMatchOut, int* dNMatches,
                                   std::string& err);
 
+int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* F1, const orbfe_frame_view* F2,
+                             int windowSize, float nnRatio, int checkOrientation, int* matches12Out, int* nMatches,
+                             std::string& err);
+
 int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const int* kfIdx, const int* fOff,
                   const int* fIdx, int nKF, const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfHasMP,
                   int nF, const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation,

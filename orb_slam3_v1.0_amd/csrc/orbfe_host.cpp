@@ -594,6 +594,22 @@ int orbfe_match_projection_batch_device(orbfe_handle* h, int batch, const orbfe_
     return rc;
 }
 
+int orbfe_match_initialization(orbfe_handle* h, const orbfe_frame_view* F1, const orbfe_frame_view* F2, int window_size,
+                               float nn_ratio, int check_orientation, int* matches12_out, int* n_matches)
+{
+    if (!h || !F1 || !F2 || !matches12_out || !n_matches || F1->n < 0 || F2->n < 0 || window_size < 0)
+        return ORBFE_ERR_INVALID_ARG;
+    if ((F1->n > 0 && (!F1->kp || !F1->desc)) || (F2->n > 0 && (!F2->kp || !F2->desc)) || F2->grid_cols < 1 || F2->grid_rows < 1)
+        return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    int rc = match_initialization_run(h->match, h->stream, F1, F2, window_size, nn_ratio, check_orientation, matches12_out,
+                                      n_matches, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
 int orbfe_match_bow(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx, const int* f_off, const int* f_idx,
                     int n_kf, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_has_mp, int n_f,
                     const uint8_t* f_desc, const float* f_angle, float nn_ratio, int check_orientation, int* match_out,

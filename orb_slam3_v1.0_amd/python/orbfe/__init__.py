@@ -51,7 +51,7 @@ SYMBOLS = [
     "orbfe_get_level_info", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
-    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
@@ -108,6 +108,7 @@ def lib():
     L.orbfe_match_projection_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp,
                                                       cf, ci, cf, cf, vp, vp, vp]
     L.orbfe_match_bow.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp, vp]
+    L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
     L.orbfe_status_string.argtypes = [ci]
     L.orbfe_status_string.restype = C.c_char_p
     L.orbfe_last_error.argtypes = [vp]
@@ -291,6 +292,15 @@ class ORBmatcher:
             self.e.h, batch, d_kp, d_desc, d_n, kp_stride, gridCols, gridRows, minX, minY, invw, invh, M, d_mps,
             d_mp_desc, d_init_obs, th, int(bFarPoints), thFarPoints, nnRatio, d_match_out, d_n_matches, stream),
             "orbfe_match_projection_batch_device")
+
+    def SearchForInitialization(self, fv1, fv2, windowSize, nnRatio, checkOrientation=True):
+        """include/ORBmatcher.h:58 -> (nmatches, vnMatches12)."""
+        out = np.full(max(1, fv1.n), -1, np.int32)
+        n = C.c_int()
+        self.e._chk(self.L.orbfe_match_initialization(self.e.h, C.byref(fv1), C.byref(fv2), int(windowSize), nnRatio,
+                                                      int(checkOrientation), _p(out), C.byref(n)),
+                    "orbfe_match_initialization")
+        return n.value, out[:fv1.n].copy()
 
     def SearchByBoW(self, kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAngle, nnRatio,
                     checkOrientation=True):

@@ -67,6 +67,7 @@ def lib():
         L.orc_search_by_projection.argtypes = [vp, ci, vp, vp, vp, cf, ci, cf, cf, vp]
         L.orc_search_by_bow.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp]
         L.orc_assign_grid.argtypes = [vp, vp]
+        L.orc_search_for_initialization.argtypes = [vp, vp, ci, cf, ci, vp]
         _lib = L
     return _lib
 
@@ -236,3 +237,9 @@ def search_by_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAn
                                 _p(kfDesc), _p(kfAngle), _p(kfHasMP), len(fDesc), _p(fDesc), _p(fAngle),
                                 nnRatio, int(checkOrientation), _p(out))
     return n, out[:len(fDesc)].copy()
+
+
+def search_for_initialization(fv1, fv2, windowSize, nnRatio, checkOrientation=True):
+    out = np.zeros(max(1, fv1.n), np.int32)
+    n = lib().orc_search_for_initialization(C.byref(fv1), C.byref(fv2), int(windowSize), nnRatio, int(checkOrientation), _p(out))
+    return n, out[:fv1.n].copy()

@@ -1,0 +1,142 @@
+"""SearchForInitialization: oracle vs an independent Python restatement (no GPU) and the
+HIP kernel vs the oracle (GPU), exact indices."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from orbfe import synth
+
+f32 = np.float32
+
+
+def _two_frames(W=320, H=240, nfeat=400, levels=4, idx0=7):
+    e = O.Extractor(nfeat, 20000, 1.2, levels, 20, 7, W, H)
+    fr = list(synth.stream(W, H, 2, index0=idx0))
+    kp1, d1, _ = e.extract(fr[0])
+    kp2, d2, _ = e.extract(fr[1])
+    return e, kp1, d1, kp2, d2
+
+
+def py_round(v):
+    return int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+
+
+def py_init(kp1, d1, kp2, d2, cols, rows, invW, invH, window, nn, orient):
+    n1, n2 = len(kp1), len(kp2)
+    grid = [[] for _ in range(cols * rows)]
+    for i in range(n2):
+        px = py_round(float(f32(f32(kp2["x"][i]) * f32(invW))))
+        py = py_round(float(f32(f32(kp2["y"][i]) * f32(invH))))
+        lin = py * cols + px
+        if 0 <= lin < cols * rows:
+            grid[lin].append(i)
+    m12 = [-1] * n1
+    m21 = [-1] * n2
+    md = [2 ** 31 - 1] * n2
+    hist = [[] for _ in range(30)]
+    nm = 0
+    r = f32(window)
+    for i1 in range(n1):
+        if kp1["octave"][i1] > 0:
+            continue
+        x, y = f32(kp1["x"][i1]), f32(kp1["y"][i1])
+        c0 = max(0, math.floor(float(f32(f32(x - r) * f32(invW)))))
+        c1 = min(cols - 1, math.ceil(float(f32(f32(x + r) * f32(invW)))))
+        r0 = max(0, math.floor(float(f32(f32(y - r) * f32(invH)))))
+        r1 = min(rows - 1, math.ceil(float(f32(f32(y + r) * f32(invH)))))
+        if c0 >= cols or c1 < 0 or r0 >= rows or r1 < 0:
+            continue
+        b1 = b2 = 2 ** 31 - 1
+        bi = -1
+        for ix in range(c0, c1 + 1):
+            for iy in range(r0, r1 + 1):
+                for j in grid[iy * cols + ix]:
+                    if kp2["octave"][j] != 0:
+                        continue
+                    if not (abs(f32(kp2["x"][j] - x)) < r and abs(f32(kp2["y"][j] - y)) < r):
+                        continue
+                    d = int(np.unpackbits(d1[i1] ^ d2[j]).sum())
+                    if md[j] <= d:
+                        continue
+                    if d < b1:
+                        b2, b1, bi = b1, d, j
+                    elif d < b2:
+                        b2 = d
+        if b1 <= 30 and f32(b1) < f32(f32(b2) * f32(nn)):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1
+                nm -= 1
+            m12[i1] = bi
+            m21[bi] = i1
+            md[bi] = b1
+            nm += 1
+            if orient:
+                rot = f32(kp1["angle"][i1] - kp2["angle"][bi])
+                if rot < 0:
+                    rot = f32(rot + f32(360.0))
+                b = py_round(float(f32(rot * f32(f32(1.0) / f32(30)))))
+                hist[0 if b == 30 else b].append(i1)
+    if orient:
+        mx = [0, 0, 0]
+        ind = [-1, -1, -1]
+        for i in range(30):
+            s = len(hist[i])
+            if s > mx[0]:
+                mx = [s, mx[0], mx[1]]; ind = [i, ind[0], ind[1]]
+            elif s > mx[1]:
+                mx = [mx[0], s, mx[1]]; ind = [ind[0], i, ind[1]]
+            elif s > mx[2]:
+                mx[2] = s; ind[2] = i
+        if f32(mx[1]) < f32(f32(0.1) * f32(mx[0])):
+            ind[1] = ind[2] = -1
+        elif f32(mx[2]) < f32(f32(0.1) * f32(mx[0])):
+            ind[2] = -1
+        for i in range(30):
+            if i in ind:
+                continue
+            for i1 in hist[i]:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    nm -= 1
+    return nm, m12
+
+
+@pytest.mark.parametrize("window,nn,orient,grid", [(40, 0.45, True, (64, 48)), (40, 0.9, True, (64, 48)),
+                                                   (100, 0.9, False, (16, 12)), (15, 0.95, True, (512, 512))])
+def test_init_oracle_equals_python(window, nn, orient, grid):
+    e, kp1, d1, kp2, d2 = _two_frames()
+    fv1 = O.make_frame_view(kp1, d1, grid[0], grid[1], 0.0, 0.0, 320.0, 240.0, e.scaleFactors)
+    fv2 = O.make_frame_view(kp2, d2, grid[0], grid[1], 0.0, 0.0, 320.0, 240.0, e.scaleFactors)
+    n, m = O.search_for_initialization(fv1, fv2, window, nn, orient)
+    n2, m2 = py_init(kp1, d1, kp2, d2, grid[0], grid[1], fv2.gridInvW, fv2.gridInvH, window, nn, orient)
+    assert n == n2 and list(m) == m2
+    assert n == sum(1 for v in m if v >= 0)
+    if nn >= 0.9 and window >= 40:
+        assert n > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,nn,orient,grid", [(40, 0.45, True, (64, 48)), (40, 0.9, True, (64, 48)),
+                                                   (100, 0.9, False, (16, 12)), (100, 0.99, True, (64, 48))])
+def test_init_hip_equals_oracle(built, window, nn, orient, grid):
+    import orbfe
+    W, H = 752, 480
+    args = (1000, 40000, 1.2, 8, 20, 7, W, H)
+    e = O.Extractor(*args)
+    fr = list(synth.stream(W, H, 2, index0=9))
+    kp1, d1, _ = e.extract(fr[0])
+    kp2, d2, _ = e.extract(fr[1])
+    f1 = O.make_frame_view(kp1, d1, grid[0], grid[1], 0.0, 0.0, float(W), float(H), e.scaleFactors)
+    f2 = O.make_frame_view(kp2, d2, grid[0], grid[1], 0.0, 0.0, float(W), float(H), e.scaleFactors)
+    n_ref, m_ref = O.search_for_initialization(f1, f2, window, nn, orient)
+    ex = orbfe.ORBextractor(*args, device=0, max_batch=1)
+    g1 = orbfe.make_frame_view(kp1, d1, grid[0], grid[1], 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    g2 = orbfe.make_frame_view(kp2, d2, grid[0], grid[1], 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    n, m = orbfe.ORBmatcher(ex).SearchForInitialization(g1, g2, window, nn, orient)
+    assert n == n_ref and np.array_equal(m, m_ref)
+    # identical frames: every level-0 keypoint matches itself at distance 0 unless the ratio test rejects it
+    n_s, m_s = orbfe.ORBmatcher(ex).SearchForInitialization(g1, g1, window, nn, orient)
+    n_so, m_so = O.search_for_initialization(f1, f1, window, nn, orient)
+    assert n_s == n_so and np.array_equal(m_s, m_so)
