@@ -1,0 +1,115 @@
+"""Edge cases on the GPU path: ragged / empty inputs, padded pitches and strides, argument validation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from orbfe import synth
+
+pytestmark = pytest.mark.gpu
+ARGS = (300, 20000, 1.2, 4, 20, 7, 320, 240)
+
+
+def test_batch_with_blank_frames_and_partial_batch(built):
+    import orbfe
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=8)
+    ref = O.Extractor(*ARGS)
+    blank = np.full((240, 320), 60, np.uint8)
+    ims = [synth.frame(320, 240, 1), blank, synth.frame(320, 240, 2), blank, blank]  # 5 of max 8
+    res = ex.extract_batch(ims)
+    assert len(res) == 5
+    for im, (kp, desc, per) in zip(ims, res):
+        kp_r, desc_r, per_r = ref.extract(im)
+        assert len(kp) == len(kp_r) and kp.tobytes() == kp_r.tobytes() and np.array_equal(desc, desc_r)
+        assert np.array_equal(per, per_r)
+    assert len(res[1][0]) == 0 and len(res[3][0]) == 0
+
+
+def test_padded_pitch_and_frame_stride(built):
+    import torch
+    import orbfe
+    W, H, B = 320, 240, 3
+    pitch, stride = 352, 352 * 250  # padded rows and padded frames
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=B)
+    ref = O.Extractor(*ARGS)
+    buf = np.random.default_rng(0).integers(0, 256, B * stride, dtype=np.uint8)  # garbage in the padding
+    ims = [synth.frame(W, H, 30 + b) for b in range(B)]
+    for b in range(B):
+        v = buf[b * stride:b * stride + H * pitch].reshape(H, pitch)
+        v[:, :W] = ims[b]
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(buf).to(dev)
+    cap = ex.cap
+    d_kp = torch.zeros(B * cap * 24, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_in.data_ptr(), stride, pitch, B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), None, None)
+    torch.cuda.synchronize(dev)
+    n = d_n.cpu().numpy()
+    kp = d_kp.cpu().numpy().view(orbfe.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+    for b in range(B):
+        kp_r, desc_r, _ = ref.extract(ims[b])
+        assert n[b] == len(kp_r) and kp[b, :n[b]].tobytes() == kp_r.tobytes() and np.array_equal(desc[b, :n[b]], desc_r)
+    # host API with a padded pitch
+    padded = np.zeros((H, pitch), np.uint8)
+    padded[:, :W] = ims[0]
+    got = ex.extractFeatures(padded[:, :W])
+    kp_r, desc_r, _ = ref.extract(ims[0])
+    assert got[0].tobytes() == kp_r.tobytes() and np.array_equal(got[1], desc_r)
+
+
+def test_matcher_empty_and_invalid_inputs(built):
+    import orbfe
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=1)
+    m = orbfe.ORBmatcher(ex)
+    kp, desc = ex.extractFeatures(synth.frame(320, 240, 5))
+    fv = orbfe.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, 320.0, 240.0, ex.mvScaleFactor)
+    # no map points
+    n, out = m.SearchByProjection(fv, np.zeros(0, orbfe.MP_DTYPE), np.zeros((0, 32), np.uint8), 20.0, False, 0.0, 0.85, None)
+    assert n == 0 and (out == -1).all()
+    # all map points filtered (not in view / bad)
+    mps = np.zeros(10, orbfe.MP_DTYPE)
+    mps["proj_x"], mps["proj_y"], mps["view_cos"] = 100, 100, 1.0
+    mps["bad"] = 1
+    mps["in_view"] = 1
+    n, out = m.SearchByProjection(fv, mps, np.zeros((10, 32), np.uint8), 20.0, False, 0.0, 0.85, None)
+    assert n == 0 and (out == -1).all()
+    # projections far outside the image: empty cell range
+    mps["bad"] = 0
+    mps["proj_x"] = 5000
+    n, out = m.SearchByProjection(fv, mps, np.zeros((10, 32), np.uint8), 20.0, False, 0.0, 0.85, None)
+    assert n == 0
+    # level out of range is rejected by the host API
+    mps["proj_x"] = 100
+    mps["level"] = 9
+    with pytest.raises(orbfe.OrbfeError) as ei:
+        m.SearchByProjection(fv, mps, np.zeros((10, 32), np.uint8), 20.0, False, 0.0, 0.85, None)
+    assert ei.value.code == 1
+    # empty frame
+    fv0 = orbfe.make_frame_view(kp[:0], desc[:0], 64, 48, 0.0, 0.0, 320.0, 240.0, ex.mvScaleFactor)
+    mps["level"] = 0
+    n, out = m.SearchByProjection(fv0, mps, np.zeros((10, 32), np.uint8), 20.0, False, 0.0, 0.85, None)
+    assert n == 0 and len(out) == 0
+    # BoW with no shared node
+    n, out = m.SearchByBoW([0], [], [0], [], desc, kp["angle"], np.ones(len(kp), np.uint8), desc, kp["angle"], 0.75, True)
+    assert n == 0 and (out == -1).all()
+    # initialization against an empty second frame
+    n, out = m.SearchForInitialization(fv, fv0, 40, 0.9, True)
+    assert n == 0 and (out == -1).all()
+
+
+def test_extract_rejects_bad_arguments(built):
+    import orbfe
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=2)
+    L = ex.L
+    img = synth.frame(320, 240, 1)
+    kp = np.zeros(ex.cap, orbfe.KP_DTYPE)
+    desc = np.zeros((ex.cap, 32), np.uint8)
+    n = C.c_int()
+    assert L.orbfe_extract(ex.h, None, 320, kp.ctypes.data, desc.ctypes.data, C.byref(n), None) == 1
+    assert L.orbfe_extract(ex.h, img.ctypes.data, 100, kp.ctypes.data, desc.ctypes.data, C.byref(n), None) == 1  # pitch < width
+    ptrs = (C.c_void_p * 3)(img.ctypes.data, img.ctypes.data, img.ctypes.data)
+    assert L.orbfe_extract_batch(ex.h, ptrs, 320, 3, kp.ctypes.data, desc.ctypes.data, C.byref(n), None) == 1  # batch > max_batch
+    assert L.orbfe_get_pyramid_level(ex.h, 0, 99, 0, kp.ctypes.data, 320) == 1
