@@ -222,6 +222,25 @@ int orbfe_match_initialization(orbfe_handle *h, const orbfe_frame_view *f1, cons
                                int *matches12_out, int *n_matches);
 
 /* -------------------------------------------------------------------------------------------
+ * Vocabulary tree: the per-feature part of Frame::ComputeBoW
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orbfe_vocab orbfe_vocab;
+
+/* Uploads a DBoW2 vocabulary tree (TemplatedVocabulary::m_nodes,
+ * Thirdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h): node 0 is the root, child_idx[child_off[i] ..
+ * child_off[i+1]) are the children of node i in DBoW2 order (a node without children is a leaf),
+ * node_desc n_nodes x 32 bytes, word_id / weight per node (read at leaves), L = m_L. */
+int orbfe_vocab_create(orbfe_handle *h, int n_nodes, const int *child_off, const int *child_idx,
+                       const uint8_t *node_desc, const int *word_id, const double *weight, int L,
+                       orbfe_vocab **out);
+void orbfe_vocab_destroy(orbfe_vocab *v);
+/* replaces TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (:1227-1270) for n
+ * descriptors at once (HOST pointers): per feature the word id, its weight and the id of the node at
+ * level L - levelsup.  The adaptor assembles BowVector / FeatureVector from these (:1136-1204). */
+int orbfe_bow_transform(orbfe_handle *h, orbfe_vocab *v, const uint8_t *desc, int n, int levelsup,
+                        int *word_id_out, int *node_id_out, double *weight_out);
+
+/* -------------------------------------------------------------------------------------------
  * Misc
  * ---------------------------------------------------------------------------------------- */
 const char *orbfe_status_string(int status);

@@ -15,7 +15,9 @@
 // classes in the reference tree and against light mock types in tests/cpp/test_adaptor.cpp.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -253,6 +255,137 @@ public:
             if (match[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[match[j]];  // :241
         return nmatches;
     }
+};
+
+// ORB_SLAM3::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:29-30), the
+// part Frame::ComputeBoW / KeyFrame::ComputeBoW use (src/Frame.cc:483-495): load the text vocabulary, transform a
+// frame's descriptors into BowVector + FeatureVector.  The tree descent of every feature runs on the GPU
+// (orbfe_bow_transform); the <= N map inserts and the normalisation stay on the host, in the reference's order, so
+// the doubles are bit-identical.  `BowVector` is any std::map<unsigned, double>-shaped type (DBoW2::BowVector),
+// `FeatureVector` any std::map<unsigned, std::vector<unsigned>>-shaped type (DBoW2::FeatureVector).
+class ORBVocabulary {
+public:
+    enum WeightingType { TF_IDF, TF, IDF, BINARY };                                        // BowVector.h:26-32
+    enum ScoringType { L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT };     // BowVector.h:35-43
+
+    explicit ORBVocabulary(orbfe_handle* h) : h_(h) {}
+    ORBVocabulary(const ORBVocabulary&) = delete;
+    ORBVocabulary& operator=(const ORBVocabulary&) = delete;
+    ~ORBVocabulary() { orbfe_vocab_destroy(v_); }
+
+    // TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1349-1436); blank lines are skipped.
+    bool loadFromTextFile(const std::string& filename)
+    {
+        FILE* f = fopen(filename.c_str(), "r");
+        if (!f) return false;
+        int n1 = 0, n2 = 0;
+        if (fscanf(f, "%d %d %d %d", &k_, &L_, &n1, &n2) != 4 || k_ < 0 || k_ > 20 || L_ < 1 || L_ > 10 || n1 < 0 || n1 > 5 ||
+            n2 < 0 || n2 > 3) {
+            fclose(f);
+            return false;
+        }
+        scoring_ = (ScoringType)n1;
+        weighting_ = (WeightingType)n2;
+        std::vector<int> parent{0}, leaf{0};
+        std::vector<uint8_t> desc(32, 0);
+        std::vector<double> weight{0.0};
+        for (;;) {
+            int pid, isLeaf;
+            if (fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;
+            uint8_t d[32];
+            bool ok = true;
+            for (int i = 0; i < 32; i++) {
+                int v;
+                ok = ok && fscanf(f, "%d", &v) == 1;
+                d[i] = (uint8_t)v;
+            }
+            double w;
+            if (!ok || fscanf(f, "%lf", &w) != 1 || pid < 0 || pid >= (int)parent.size()) {
+                fclose(f);
+                return false;
+            }
+            parent.push_back(pid);
+            leaf.push_back(isLeaf);
+            desc.insert(desc.end(), d, d + 32);
+            weight.push_back(w);
+        }
+        fclose(f);
+        const int n = (int)parent.size();
+        std::vector<int> childOff(n + 1, 0), childIdx(n > 1 ? n - 1 : 1), wordId(n, 0);
+        for (int i = 1; i < n; i++) childOff[parent[i] + 1]++;
+        for (int i = 0; i < n; i++) childOff[i + 1] += childOff[i];
+        std::vector<int> fill(childOff.begin(), childOff.end() - 1);
+        for (int i = 1; i < n; i++) childIdx[fill[parent[i]]++] = i;  // ascending id == push_back order (:1403)
+        nWords_ = 0;
+        for (int i = 1; i < n; i++)
+            if (leaf[i] > 0) wordId[i] = nWords_++;  // :1419-1426
+        return create(n, childOff.data(), childIdx.data(), desc.data(), wordId.data(), weight.data(), L_);
+    }
+
+    // direct construction from DBoW2's node table (for callers that already hold one)
+    bool create(int nNodes, const int* childOff, const int* childIdx, const uint8_t* nodeDesc, const int* wordId,
+                const double* weight, int L)
+    {
+        orbfe_vocab_destroy(v_);
+        v_ = nullptr;
+        L_ = L;
+        return orbfe_vocab_create(h_, nNodes, childOff, childIdx, nodeDesc, wordId, weight, L, &v_) == ORBFE_OK;
+    }
+
+    bool empty() const { return v_ == nullptr; }
+    unsigned size() const { return (unsigned)nWords_; }
+    int getBranchingFactor() const { return k_; }
+    int getDepthLevels() const { return L_; }
+    void setScoringType(ScoringType t) { scoring_ = t; }
+    void setWeightingType(WeightingType t) { weighting_ = t; }
+
+    // TemplatedVocabulary::transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1136-1204); `desc` is the
+    // frame's N x 32 descriptor matrix (what Converter::toDescriptorVector splits into rows, src/Frame.cc:487).
+    template <class BowVector, class FeatureVector>
+    void transform(const uint8_t* desc, int n, BowVector& v, FeatureVector& fv, int levelsup) const
+    {
+        v.clear();
+        fv.clear();
+        if (empty() || n <= 0) return;
+        std::vector<int> word(n), node(n);
+        std::vector<double> w(n);
+        orbfe_detail::check(orbfe_bow_transform(h_, v_, desc, n, levelsup, word.data(), node.data(), w.data()), h_,
+                            "orbfe_bow_transform");
+        const bool must = scoring_ != DOT_PRODUCT;  // ScoringObject.h:74-89
+        const bool tf = weighting_ == TF || weighting_ == TF_IDF;
+        for (int i = 0; i < n; i++) {
+            if (!(w[i] > 0)) continue;  // stopped word
+            auto it = v.lower_bound(word[i]);
+            if (it != v.end() && !(v.key_comp()(word[i], it->first))) {
+                if (tf) it->second += w[i];  // BowVector::addWeight; addIfNotExist leaves it
+            } else {
+                v.insert(it, typename BowVector::value_type(word[i], w[i]));
+            }
+            fv[node[i]].push_back(i);  // FeatureVector::addFeature
+        }
+        if (tf && !v.empty() && !must) {
+            const double nd = (double)v.size();
+            for (auto& e : v) e.second /= nd;
+        }
+        if (must) {  // BowVector::normalize, src/DBoW2/BowVector.cpp:62-84
+            double norm = 0.0;
+            if (scoring_ == L2_NORM) {
+                for (auto& e : v) norm += e.second * e.second;
+                norm = std::sqrt(norm);
+            } else {
+                for (auto& e : v) norm += std::fabs(e.second);
+            }
+            if (norm > 0.0)
+                for (auto& e : v) e.second /= norm;
+        }
+    }
+
+private:
+    orbfe_handle* h_;
+    orbfe_vocab* v_ = nullptr;
+    int k_ = 0, L_ = 0, nWords_ = 0;
+    ScoringType scoring_ = L1_NORM;
+    WeightingType weighting_ = TF_IDF;
 };
 
 }  // namespace ORB_SLAM3

@@ -351,3 +351,41 @@ int orc_search_for_initialization(const orc_frame_view *F1, const orc_frame_view
     free_grid(F2, g);
     return nmatches;
 }
+
+/* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup),
+ * Thirdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:1227-1270, with FORB::distance
+ * (Thirdparty/DBoW2/src/DBoW2/FORB.cpp:81-101).  The tree is given as CSR children lists in DBoW2's
+ * child order; node 0 is the root; a node without children is a leaf.  S7: when a leaf is reached above
+ * level L - levelsup the reference leaves nid uninitialised; the oracle returns the leaf's id. */
+void orc_vocab_transform(int nNodes, const int *childOff, const int *childIdx, const uint8_t *nodeDesc,
+                         const int *wordId, const double *weight, int L, const uint8_t *desc, int n,
+                         int levelsup, int *wordOut, int *nodeOut, double *weightOut)
+{
+    (void)nNodes;
+    for (int f = 0; f < n; f++) {
+        const uint8_t *feature = desc + (size_t)f * 32;
+        const int nid_level = L - levelsup;
+        int nid = -1;
+        if (nid_level <= 0) nid = 0;
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const int c0 = childOff[final_id], c1 = childOff[final_id + 1];
+            final_id = childIdx[c0];
+            double best_d = (double)orc_hamming(feature, nodeDesc + (size_t)final_id * 32);
+            for (int j = c0 + 1; j < c1; j++) {
+                const int id = childIdx[j];
+                const double d = (double)orc_hamming(feature, nodeDesc + (size_t)id * 32);
+                if (d < best_d) {
+                    best_d = d;
+                    final_id = id;
+                }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (childOff[final_id + 1] != childOff[final_id]);
+        if (nid < 0) nid = final_id; /* S7 */
+        wordOut[f] = wordId[final_id];
+        nodeOut[f] = nid;
+        if (weightOut) weightOut[f] = weight[final_id];
+    }
+}

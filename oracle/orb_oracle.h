@@ -125,6 +125,12 @@ int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff
 int orc_search_for_initialization(const orc_frame_view *F1, const orc_frame_view *F2, int windowSize,
                                   float nnRatio, int checkOrientation, int *matches12Out);
 
+/* TemplatedVocabulary::transform(feature, ...) (Thirdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:1227-1270)
+ * for n descriptors; tree as CSR children lists, node 0 = root, leaf = node without children. */
+void orc_vocab_transform(int nNodes, const int *childOff, const int *childIdx, const uint8_t *nodeDesc,
+                         const int *wordId, const double *weight, int L, const uint8_t *desc, int n,
+                         int levelsup, int *wordOut, int *nodeOut, double *weightOut);
+
 /* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480): linear cell per kp or -1 */
 void orc_assign_grid(const orc_frame_view *F, int *cellOut);
 

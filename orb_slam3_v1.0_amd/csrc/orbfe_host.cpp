@@ -16,6 +16,7 @@
 
 #include "launch.h"
 #include "match.h"
+#include "vocab.h"
 
 using namespace orbfe;
 
@@ -606,6 +607,50 @@ int orbfe_match_initialization(orbfe_handle* h, const orbfe_frame_view* F1, cons
     std::string err;
     int rc = match_initialization_run(h->match, h->stream, F1, F2, window_size, nn_ratio, check_orientation, matches12_out,
                                       n_matches, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+struct orbfe_vocab {
+    orbfe::Vocab* v;
+    int device;
+};
+
+int orbfe_vocab_create(orbfe_handle* h, int n_nodes, const int* child_off, const int* child_idx, const uint8_t* node_desc,
+                       const int* word_id, const double* weight, int L, orbfe_vocab** out)
+{
+    if (!h || !child_off || !child_idx || !node_desc || !word_id || !weight || !out || n_nodes < 2 || L < 1)
+        return ORBFE_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    orbfe::Vocab* v = nullptr;
+    const int rc = vocab_create(n_nodes, child_off, child_idx, node_desc, word_id, weight, L, &v, err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    *out = new orbfe_vocab{v, h->device};
+    return ORBFE_OK;
+}
+
+void orbfe_vocab_destroy(orbfe_vocab* v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    vocab_destroy(v->v);
+    delete v;
+}
+
+int orbfe_bow_transform(orbfe_handle* h, orbfe_vocab* v, const uint8_t* desc, int n, int levelsup, int* word_id_out,
+                        int* node_id_out, double* weight_out)
+{
+    if (!h || !v || n < 0 || (n > 0 && (!desc || !word_id_out || !node_id_out))) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = vocab_transform(v->v, h->stream, desc, n, levelsup, word_id_out, node_id_out, weight_out, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
 }

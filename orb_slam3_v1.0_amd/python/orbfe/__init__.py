@@ -51,7 +51,7 @@ SYMBOLS = [
     "orbfe_get_level_info", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
-    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
@@ -109,6 +109,10 @@ def lib():
                                                       cf, ci, cf, cf, vp, vp, vp]
     L.orbfe_match_bow.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp, vp]
     L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
+    L.orbfe_vocab_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, C.POINTER(vp)]
+    L.orbfe_vocab_destroy.argtypes = [vp]
+    L.orbfe_vocab_destroy.restype = None
+    L.orbfe_bow_transform.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp]
     L.orbfe_status_string.argtypes = [ci]
     L.orbfe_status_string.restype = C.c_char_p
     L.orbfe_last_error.argtypes = [vp]
@@ -318,3 +322,113 @@ class ORBmatcher:
                                            _p(fAngle), nnRatio, int(checkOrientation), _p(out), C.byref(n)),
                     "orbfe_match_bow")
         return n.value, out[:len(fDesc)].copy()
+
+
+class ORBVocabulary:
+    """Device copy of a DBoW2 vocabulary tree + the per-feature descent of Frame::ComputeBoW
+    (src/Frame.cc:483-495 -> TemplatedVocabulary::transform)."""
+
+    def __init__(self, extractor, childOff, childIdx, nodeDesc, wordId, weight, L):
+        self.e, self.L_ = extractor, extractor.L
+        a32 = lambda v: np.ascontiguousarray(v, np.int32)
+        self._keep = (a32(childOff), a32(childIdx), np.ascontiguousarray(nodeDesc, np.uint8), a32(wordId),
+                      np.ascontiguousarray(weight, np.float64))
+        self.v = C.c_void_p()
+        co, ci_, nd, wi, we = self._keep
+        extractor._chk(self.L_.orbfe_vocab_create(extractor.h, len(wi), _p(co), _p(ci_), _p(nd), _p(wi), _p(we), int(L),
+                                                  C.byref(self.v)), "orbfe_vocab_create")
+
+    def close(self):
+        if getattr(self, "v", None):
+            self.L_.orbfe_vocab_destroy(self.v)
+            self.v = None
+
+    __del__ = close
+
+    def transform(self, desc, levelsup):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        word = np.zeros(max(n, 1), np.int32)
+        node = np.zeros(max(n, 1), np.int32)
+        weight = np.zeros(max(n, 1), np.float64)
+        self.e._chk(self.L_.orbfe_bow_transform(self.e.h, self.v, _p(desc), n, levelsup, _p(word), _p(node), _p(weight)),
+                    "orbfe_bow_transform")
+        return word[:n], node[:n], weight[:n]
+
+    # weighting / scoring enums of DBoW2 (TemplatedVocabulary.h:35-55)
+    TF_IDF, TF, IDF, BINARY = 0, 1, 2, 3
+    L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT = 0, 1, 2, 3, 4, 5
+
+    def transform_bow(self, desc, levelsup, weighting=0, scoring=0):
+        """TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+        (TemplatedVocabulary.h:1136-1204) as Frame::ComputeBoW calls it (src/Frame.cc:483-495, levelsup 4).
+        The per-feature tree descent runs on the GPU; the map assembly (<= N inserts) stays on the host in the
+        reference's order so the doubles come out bit-identical.  Returns (BowVector, FeatureVector) as dicts
+        in ascending key order (std::map iteration order)."""
+        word, node, w = self.transform(desc, levelsup)
+        bow, fv = {}, {}
+        tf = weighting in (self.TF_IDF, self.TF)
+        for i in range(len(word)):
+            wi = float(w[i])
+            if wi > 0:
+                k = int(word[i])
+                if tf:
+                    bow[k] = bow.get(k, 0.0) + wi      # BowVector::addWeight
+                elif k not in bow:
+                    bow[k] = wi                        # BowVector::addIfNotExist
+                fv.setdefault(int(node[i]), []).append(i)  # FeatureVector::addFeature
+        bow = dict(sorted(bow.items()))
+        fv = dict(sorted(fv.items()))
+        must = scoring != self.DOT_PRODUCT
+        if tf and bow and not must:
+            nd = float(len(bow))
+            for k in bow:
+                bow[k] /= nd
+        if must:                                       # BowVector::normalize (src/DBoW2/BowVector.cpp:62-84)
+            norm = 0.0
+            if scoring == self.L2_NORM:
+                for v in bow.values():
+                    norm += v * v
+                norm = float(np.sqrt(np.float64(norm)))
+            else:
+                for v in bow.values():
+                    norm += abs(v)
+            if norm > 0.0:
+                for k in bow:
+                    bow[k] /= norm
+        return bow, fv
+
+
+def load_vocabulary_text(path):
+    """Parse the ORBvoc.txt format of TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1349-1436)
+    into the CSR tree orbfe_vocab_create takes.  Returns a dict with k, L, scoring, weighting, childOff,
+    childIdx, nodeDesc, wordId, weight.  Blank lines are skipped (the reference would read a node from
+    them with an indeterminate parent)."""
+    with open(path) as f:
+        k, L, scoring, weighting = (int(t) for t in f.readline().split()[:4])
+        if k < 0 or k > 20 or L < 1 or L > 10 or scoring < 0 or scoring > 5 or weighting < 0 or weighting > 3:
+            raise ValueError("not a DBoW2 text vocabulary: %s" % path)
+        parent, desc, weight, leaf = [0], [np.zeros(32, np.uint8)], [0.0], [0]
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            parent.append(int(t[0]))
+            leaf.append(int(t[1]))
+            desc.append(np.array([int(v) for v in t[2:34]], np.uint8))
+            weight.append(float(t[34]))
+    n = len(parent)
+    kids = [[] for _ in range(n)]
+    for i in range(1, n):
+        kids[parent[i]].append(i)
+    childOff = np.zeros(n + 1, np.int32)
+    childOff[1:] = np.cumsum([len(c) for c in kids])
+    childIdx = np.array([c for cs in kids for c in cs], np.int32)
+    wordId = np.zeros(n, np.int32)  # Node::word_id defaults to 0 (TemplatedVocabulary.h:275)
+    nw = 0
+    for i in range(1, n):
+        if leaf[i] > 0:
+            wordId[i] = nw
+            nw += 1
+    return dict(k=k, L=L, scoring=scoring, weighting=weighting, childOff=childOff, childIdx=childIdx,
+                nodeDesc=np.stack(desc), wordId=wordId, weight=np.array(weight, np.float64))

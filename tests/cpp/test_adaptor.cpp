@@ -1,6 +1,6 @@
 // Drives include/orbfe_adaptor.hpp the way src/Frame.cc:178-189 and src/Tracking.cc:1115 drive the
 // reference classes, with light mock Frame / MapPoint types that carry the members those functions read.
-//   usage: test_adaptor <W> <H> <gray.raw> <mps.bin> <M> <out.bin>
+//   usage: test_adaptor <W> <H> <gray.raw> <mps.bin> <M> <out.bin> [<voc.txt> <bow_out.txt>]
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -83,6 +83,22 @@ int main(int argc, char** argv)
         for (int j = 0; j < M && F->mvpMapPoints[i]; j++)
             if (mps[j] == F->mvpMapPoints[i]) { idx = j; break; }
         o.write((const char*)&idx, 4);
+    }
+    if (argc >= 9) {  // Frame::ComputeBoW, src/Frame.cc:483-495: mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)
+        ORBVocabulary voc(ex.handle());
+        if (!voc.loadFromTextFile(argv[7])) { std::puts("vocabulary load failed"); return 3; }
+        std::map<unsigned, double> bowVec;                    // DBoW2::BowVector
+        std::map<unsigned, std::vector<unsigned>> featVec;    // DBoW2::FeatureVector
+        voc.transform(desc.data(), n, bowVec, featVec, 4);
+        FILE* fo = fopen(argv[8], "w");
+        std::fprintf(fo, "%zu %zu %u\n", bowVec.size(), featVec.size(), voc.size());
+        for (auto& e : bowVec) std::fprintf(fo, "%u %a\n", e.first, e.second);
+        for (auto& e : featVec) {
+            std::fprintf(fo, "%u %zu", e.first, e.second.size());
+            for (unsigned i : e.second) std::fprintf(fo, " %u", i);
+            std::fprintf(fo, "\n");
+        }
+        fclose(fo);
     }
     std::printf("adaptor ok: %d keypoints, %d matches, levels=%d scale=%g\n", n, nm, ex.GetLevels(), ex.GetScaleFactor());
     return 0;

@@ -68,6 +68,8 @@ def lib():
         L.orc_search_by_bow.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp]
         L.orc_assign_grid.argtypes = [vp, vp]
         L.orc_search_for_initialization.argtypes = [vp, vp, ci, cf, ci, vp]
+        L.orc_vocab_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, vp]
+        L.orc_vocab_transform.restype = None
         _lib = L
     return _lib
 
@@ -243,3 +245,18 @@ def search_for_initialization(fv1, fv2, windowSize, nnRatio, checkOrientation=Tr
     out = np.zeros(max(1, fv1.n), np.int32)
     n = lib().orc_search_for_initialization(C.byref(fv1), C.byref(fv2), int(windowSize), nnRatio, int(checkOrientation), _p(out))
     return n, out[:fv1.n].copy()
+
+
+def vocab_transform(childOff, childIdx, nodeDesc, wordId, weight, L, desc, levelsup):
+    a32 = lambda v: np.ascontiguousarray(v, np.int32)
+    childOff, childIdx, wordId = a32(childOff), a32(childIdx), a32(wordId)
+    nodeDesc = np.ascontiguousarray(nodeDesc, np.uint8)
+    weight = np.ascontiguousarray(weight, np.float64)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    word = np.zeros(max(n, 1), np.int32)
+    node = np.zeros(max(n, 1), np.int32)
+    w = np.zeros(max(n, 1), np.float64)
+    lib().orc_vocab_transform(len(wordId), _p(childOff), _p(childIdx), _p(nodeDesc), _p(wordId), _p(weight), int(L),
+                              _p(desc), n, int(levelsup), _p(word), _p(node), _p(w))
+    return word[:n], node[:n], w[:n]

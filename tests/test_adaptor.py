@@ -42,7 +42,12 @@ def test_adaptor_matches_oracle(built, tmp_path):
     rec = np.zeros(M, np.dtype([("mp", O.MP_DTYPE), ("d", np.uint8, 32)]))
     rec["mp"], rec["d"] = mps, mpd
     (tmp_path / "m.bin").write_bytes(rec.tobytes())
-    subprocess.check_call([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "m.bin"), str(M), str(tmp_path / "o.bin")])
+    import vocab_synth as vs
+    from test_vocab import ref_bow
+    tree = vs.make_tree(10, 5, seed=9, early_leaf_p=0.03)
+    vs.write_text(tree, str(tmp_path / "voc.txt"))
+    subprocess.check_call([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "m.bin"), str(M), str(tmp_path / "o.bin"),
+                           str(tmp_path / "voc.txt"), str(tmp_path / "bow.txt")])
     raw = (tmp_path / "o.bin").read_bytes()
     n, nm = np.frombuffer(raw[:8], np.int32)
     kp = np.frombuffer(raw[8:8 + 24 * n], orbfe.KP_DTYPE)
@@ -50,3 +55,14 @@ def test_adaptor_matches_oracle(built, tmp_path):
     match = np.frombuffer(raw[8 + 56 * n:], np.int32)
     assert n == len(kp_r) and kp.tobytes() == kp_r.tobytes() and np.array_equal(desc, desc_r)
     assert nm == n_ref and np.array_equal(match, out_ref)
+    # Frame::ComputeBoW through ORBVocabulary::transform (levelsup 4, TF_IDF + L1 as ORBvoc.txt declares)
+    ow, on, owt = O.vocab_transform(tree["childOff"], tree["childIdx"], tree["nodeDesc"], tree["wordId"], tree["weight"],
+                                    tree["L"], desc_r, 4)
+    rb, rf = ref_bow(ow, on, owt, 0, 0)
+    lines = (tmp_path / "bow.txt").read_text().split("\n")
+    nb, nf, nw = (int(t) for t in lines[0].split())
+    assert nw == tree["nWords"] and nb == len(rb) and nf == len(rf)
+    got_b = [(int(l.split()[0]), float.fromhex(l.split()[1])) for l in lines[1:1 + nb]]
+    assert got_b == list(rb.items())
+    got_f = {int(l.split()[0]): [int(t) for t in l.split()[2:]] for l in lines[1 + nb:1 + nb + nf]}
+    assert got_f == rf
