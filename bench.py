@@ -297,7 +297,7 @@ def main():
                          "extract_pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
                          "stage_ms_per_step": stage_avg},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             fps, n = cpu_baseline(cfg, frames[:64], a.cpu_seconds, bool(M), orbfe.MP_DTYPE)
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d frames of the same stream through the single-thread C oracle (%s), "

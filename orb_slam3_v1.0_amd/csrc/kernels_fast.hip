@@ -63,10 +63,12 @@ __device__ __forceinline__ int arc_max_min(const int (&a)[16])
 // `p` points at the centre pixel inside the staged tile (row pitch kImgW).
 __device__ __forceinline__ bool compass_pass_ptr(const uint8_t* p, int th)
 {
+    // the compass cycle 0-4-8-12 is bipartite ({0,8} vs {4,12}) and every cross pair is adjacent, so
+    // "some adjacent pair is bright" == (0 or 8 bright) and (4 or 12 bright); same for dark
     const int v = p[0];
     const int d0 = p[3 * kImgW] - v, d4 = p[3] - v, d8 = p[-3 * kImgW] - v, d12 = p[-3] - v;
-    const int hiPair = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
-    const int loPair = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+    const int hiPair = min(max(d0, d8), max(d4, d12));
+    const int loPair = max(min(d0, d8), min(d4, d12));
     return hiPair > th || loPair < -th;
 }
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
 {
     __shared__ uint32_t sRow[kFastTH];  // pre-NMS corners per tile row: low-pass count | high-pass count << 16
     __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH][kImgW];
-    __shared__ __attribute__((aligned(16))) uint16_t sTmp[kTmpH][kFastTW];
+    __shared__ __attribute__((aligned(16))) uint32_t sTmp[kTmpH / 2][kFastTW];  // row pairs of horizontal sums
     __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH][kScPitch];
     __shared__ uint32_t sCnt4[4];  // per-wave totals of the stage-A scan
     __shared__ uint32_t sCand[kMaxTileCand];
@@ -148,8 +150,11 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int f = blockIdx.x;
     const int tile = blockIdx.y;
     const int nL = P->nLevels;
+    // tile -> level without a chain of dependent scalar loads: the first 8 bases arrive in one load
     int l = 0;
-    while (l + 1 < nL && tile >= P->lv[l + 1].tileBase) l++;
+#pragma unroll
+    for (int i = 1; i < 8; i++) l = tile >= P->tileBaseTab[i] ? i : l;
+    while (l + 1 < nL && tile >= P->lv[l + 1].tileBase) l++;  // levels >= 8 (rare)
     const LevelDesc& L = P->lv[l];
     const int w = L.w, h = L.h;
     const int t = tile - L.tileBase;
@@ -176,79 +181,136 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     if (tid < 2) sQ[tid] = 0;
     if (tid < kFastTH) sRow[tid] = 0;
 
-    // ---- stage the 72 x 40 tile (origin x0-4, y0-4); pixels outside the level follow
-    //      BORDER_REFLECT_101 (needed by the blur; FAST never looks at them) ----
-    for (int e = tid; e < kImgH * (kImgW / 4); e += 256) {
-        const int r = e / (kImgW / 4);
-        const int c4 = e - r * (kImgW / 4);
-        const int gy = reflect_near(y0 - 4 + r, h);
-        const int gx = x0 - 4 + 4 * c4;
-        const uint8_t* row = src + (size_t)gy * spitch;
-        uint32_t wv;
-        if (aligned && gx >= 0 && gx + 3 < w) {
-            wv = *reinterpret_cast<const uint32_t*>(row + gx);
-        } else {
-            wv = 0;
+    // ---- stage the 72 x 40 tile (origin x0-4, y0-4).  Thread -> fixed dword column c4 (18 per row) and
+    //      rows r0, r0+14, r0+28: the three loads are issued back to back.  Rows outside the level follow
+    //      BORDER_REFLECT_101 through the row address; dwords that start inside the row are loaded whole (the
+    //      bytes past w lie inside the pitch), columns outside the level are patched from LDS afterwards
+    //      (only the 2 nearest are ever read, by the blur; FAST never looks outside the level) ----
+    if (aligned) {
+        if (tid < 14 * (kImgW / 4)) {
+            const int r0 = tid / (kImgW / 4);
+            const int c4 = tid - r0 * (kImgW / 4);
+            const int gx = x0 - 4 + 4 * c4;
+            const bool colIn = gx >= 0 && gx < w;
+            uint32_t wv[3];
 #pragma unroll
-            for (int i = 0; i < 4; i++) wv |= (uint32_t)row[reflect_near(gx + i, w)] << (8 * i);
+            for (int k = 0; k < 3; k++) {
+                const int r = r0 + 14 * k;
+                wv[k] = 0;
+                if (colIn && r < kImgH)
+                    wv[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect_near(y0 - 4 + r, h) * spitch + gx);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int r = r0 + 14 * k;
+                if (colIn && r < kImgH) *reinterpret_cast<uint32_t*>(&sImg[r][4 * c4]) = wv[k];
+            }
         }
-        *reinterpret_cast<uint32_t*>(&sImg[r][4 * c4]) = wv;
+        const int cR = w - x0 + 4;  // LDS column of image column w
+        const bool patchL = x0 == 0, patchR = cR + 1 < kImgW;
+        if (patchL || patchR) {  // block-uniform: border tiles only
+            __syncthreads();
+            if (tid < kImgH) {
+                if (patchL) {
+                    sImg[tid][2] = sImg[tid][6];  // col -2 <- col 2
+                    sImg[tid][3] = sImg[tid][5];  // col -1 <- col 1
+                }
+            } else if (tid >= 64 && tid < 64 + kImgH) {
+                if (patchR) {
+                    sImg[tid - 64][cR] = sImg[tid - 64][cR - 2];      // col w   <- col w-2
+                    sImg[tid - 64][cR + 1] = sImg[tid - 64][cR - 3];  // col w+1 <- col w-3
+                }
+            }
+        }
+    } else {
+        // level 0 handed over with an odd base address or pitch: byte loads
+        for (int e = tid; e < kImgH * (kImgW / 4); e += 256) {
+            const int r = e / (kImgW / 4);
+            const int c4 = e - r * (kImgW / 4);
+            const uint8_t* row = src + (size_t)reflect_near(y0 - 4 + r, h) * spitch;
+            uint32_t wv = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) wv |= (uint32_t)row[reflect_near(x0 - 4 + 4 * c4 + i, w)] << (8 * i);
+            *reinterpret_cast<uint32_t*>(&sImg[r][4 * c4]) = wv;
+        }
     }
     __syncthreads();
 
     if constexpr ((MODE & 1) != 0) {
     // ================= Gaussian 5x5 of the tile (S1) =================
-    // horizontal: output column xl (0..63) of row rr (image row y0-2+rr) taps LDS cols xl+2..xl+6
-    for (int e = tid; e < kTmpH * (kFastTW / 4); e += 256) {
-        const int rr = e / (kFastTW / 4);
-        const int xl = (e - rr * (kFastTW / 4)) * 4;
-        const uint32_t* rowp = reinterpret_cast<const uint32_t*>(&sImg[rr + 2][xl]);
-        const uint32_t w0 = rowp[0], w1 = rowp[1], w2 = rowp[2];
-        uint32_t b[12];
+    // horizontal: item = (row pair j, 4 output columns xl..xl+3); output column x of tmp row rr (image
+    // row y0-2+rr) taps LDS cols x+2..x+6.  Byte windows via v_alignbyte, 4 taps per v_dot4_u32_u8:
+    // o = dot4(bytes x+2..x+5, {22,62,88,62}) + dot4(bytes x+3..x+6, {0,0,0,22})  (<= 65280).
+    // sTmp holds row PAIRS: dword [j][x] = tmp row 2j (low half) | tmp row 2j+1 (high half), so the vertical
+    // pass is three v_dot2_u32_u16 per output.
+    for (int e = tid; e < (kTmpH / 2) * (kFastTW / 4); e += 256) {
+        const int j = e / (kFastTW / 4);
+        const int xl = (e - j * (kFastTW / 4)) * 4;
+        uint32_t o[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            b[i] = (w0 >> (8 * i)) & 0xff;
-            b[4 + i] = (w1 >> (8 * i)) & 0xff;
-            b[8 + i] = (w2 >> (8 * i)) & 0xff;
+        for (int half = 0; half < 2; half++) {
+            const uint32_t* rowp = reinterpret_cast<const uint32_t*>(&sImg[2 * j + half + 2][xl]);
+            const uint32_t w0 = rowp[0], w1 = rowp[1], w2 = rowp[2];
+            uint32_t win[5];
+            win[0] = __builtin_amdgcn_alignbyte(w1, w0, 2);  // bytes 2..5
+            win[1] = __builtin_amdgcn_alignbyte(w1, w0, 3);  // bytes 3..6
+            win[2] = w1;                                     // bytes 4..7
+            win[3] = __builtin_amdgcn_alignbyte(w2, w1, 1);  // bytes 5..8
+            win[4] = __builtin_amdgcn_alignbyte(w2, w1, 2);  // bytes 6..9
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                o[half][i] = __builtin_amdgcn_udot4(win[i + 1], 0x16000000u,
+                                                    __builtin_amdgcn_udot4(win[i], 0x3E583E16u, 0u, false), false);
         }
-        uint32_t o[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            o[i] = 22u * b[i + 2] + 62u * b[i + 3] + 88u * b[i + 4] + 62u * b[i + 5] + 22u * b[i + 6];  // <= 65280
-        uint2 pk;
-        pk.x = o[0] | (o[1] << 16);
-        pk.y = o[2] | (o[3] << 16);
-        *reinterpret_cast<uint2*>(&sTmp[rr][xl]) = pk;
+        uint4 pk;
+        pk.x = o[0][0] | (o[1][0] << 16);
+        pk.y = o[0][1] | (o[1][1] << 16);
+        pk.z = o[0][2] | (o[1][2] << 16);
+        pk.w = o[0][3] | (o[1][3] << 16);
+        *reinterpret_cast<uint4*>(&sTmp[j][xl]) = pk;
     }
     __syncthreads();
-    // vertical: thread -> 4 columns x 2 rows (rows yp and yp+16), one rounding (+32768 >> 16)
+    // vertical: thread -> 4 columns x output rows 2*yp, 2*yp+1 (tmp rows 2yp..2yp+5 = pairs yp..yp+2), one
+    // rounding (+32768 >> 16) folded into the accumulator init; the result is byte 2 of each accumulator
     {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         uint8_t* dst = ws + L.blurOff + (size_t)f * L.blurFrameStride;
         const int dpitch = L.pitch;
         const int xl = (tid & 15) * 4;
         const int yp = tid >> 4;  // 0..15
+        const int gy = y0 + 2 * yp, gx = x0 + xl;
+        if (gy < h && gx < w) {
+            const uint4 p0 = *reinterpret_cast<const uint4*>(&sTmp[yp][xl]);
+            const uint4 p1 = *reinterpret_cast<const uint4*>(&sTmp[yp + 1][xl]);
+            const uint4 p2 = *reinterpret_cast<const uint4*>(&sTmp[yp + 2][xl]);
+            const uint32_t c0[4] = {p0.x, p0.y, p0.z, p0.w}, c1[4] = {p1.x, p1.y, p1.z, p1.w}, c2[4] = {p2.x, p2.y, p2.z, p2.w};
+            uint32_t ev[4], od[4];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int yl = yp + 16 * half;
-            const int gy = y0 + yl, gx = x0 + xl;
-            if (gy < h && gx < w) {
-                uint32_t acc[4] = {0, 0, 0, 0};
-                const uint32_t kw[5] = {22u, 62u, 88u, 62u, 22u};
-#pragma unroll
-                for (int tt = 0; tt < 5; tt++) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(&sTmp[yl + tt][xl]);
-                    acc[0] += kw[tt] * (v.x & 0xffffu);
-                    acc[1] += kw[tt] * (v.x >> 16);
-                    acc[2] += kw[tt] * (v.y & 0xffffu);
-                    acc[3] += kw[tt] * (v.y >> 16);
-                }
-                const uint32_t outw = ((acc[0] + 32768u) >> 16) | (((acc[1] + 32768u) >> 16) << 8) |
-                                      (((acc[2] + 32768u) >> 16) << 16) | (((acc[3] + 32768u) >> 16) << 24);
-                uint8_t* drow = dst + (size_t)gy * dpitch;
-                if (gx + 3 < w) {
-                    *reinterpret_cast<uint32_t*>(drow + gx) = outw;  // dpitch % 64 == 0, gx % 4 == 0
-                } else {
-                    for (int i = 0; gx + i < w; i++) drow[gx + i] = (uint8_t)(outw >> (8 * i));
+            for (int i = 0; i < 4; i++) {
+                const us2 a = __builtin_bit_cast(us2, c0[i]), b = __builtin_bit_cast(us2, c1[i]), c = __builtin_bit_cast(us2, c2[i]);
+                // even row 2yp: tmp rows 2yp..2yp+4 -> taps (22,62 | 88,62 | 22,-)
+                uint32_t acc = __builtin_amdgcn_udot2(a, __builtin_bit_cast(us2, 0x003E0016u), 32768u, false);
+                acc = __builtin_amdgcn_udot2(b, __builtin_bit_cast(us2, 0x003E0058u), acc, false);
+                ev[i] = __builtin_amdgcn_udot2(c, __builtin_bit_cast(us2, 0x00000016u), acc, false);
+                // odd row 2yp+1: tmp rows 2yp+1..2yp+5 -> taps (-,22 | 62,88 | 62,22)
+                acc = __builtin_amdgcn_udot2(a, __builtin_bit_cast(us2, 0x00160000u), 32768u, false);
+                acc = __builtin_amdgcn_udot2(b, __builtin_bit_cast(us2, 0x0058003Eu), acc, false);
+                od[i] = __builtin_amdgcn_udot2(c, __builtin_bit_cast(us2, 0x0016003Eu), acc, false);
+            }
+            // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00
+            const uint32_t outE = __builtin_amdgcn_perm(ev[1], ev[0], 0x0c0c0602u) |
+                                  (__builtin_amdgcn_perm(ev[3], ev[2], 0x0c0c0602u) << 16);
+            const uint32_t outO = __builtin_amdgcn_perm(od[1], od[0], 0x0c0c0602u) |
+                                  (__builtin_amdgcn_perm(od[3], od[2], 0x0c0c0602u) << 16);
+            uint8_t* drow = dst + (size_t)gy * dpitch;
+            const bool odd = gy + 1 < h;
+            if (gx + 3 < w) {
+                *reinterpret_cast<uint32_t*>(drow + gx) = outE;  // dpitch % 64 == 0, gx % 4 == 0
+                if (odd) *reinterpret_cast<uint32_t*>(drow + dpitch + gx) = outO;
+            } else {
+                for (int i = 0; gx + i < w; i++) {
+                    drow[gx + i] = (uint8_t)(outE >> (8 * i));
+                    if (odd) drow[dpitch + gx + i] = (uint8_t)(outO >> (8 * i));
                 }
             }
         }

@@ -270,6 +270,7 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     }
     P.kpCapFrame = kpBase;
     P.totalTiles = tileBase;
+    for (int l = 0; l < 8; l++) P.tileBaseTab[l] = l < nL ? P.lv[l].tileBase : 0x7fffffff;
     h->wsBytes = wsOff;
     h->candWordsPerBatch = candOff;
 

@@ -69,6 +69,7 @@ struct PipelineDesc {
     int iniTh, minTh;
     int kpCapFrame;           // sum of nodeCap == orbfe_max_keypoints
     int totalTiles;           // FAST tiles per frame over all levels
+    int tileBaseTab[8];       // lv[0..7].tileBase in one s_load_dwordx8 (INT_MAX beyond nLevels)
     LevelDesc lv[kMaxLevels];
 };
 

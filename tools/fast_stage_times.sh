@@ -1,0 +1,8 @@
+#!/bin/bash
+# per-stage time of fast_blur_kernel via the timing-only ablation modes (ORBFE_FAST_MODE):
+# 0 = staging only, 1 = +blur, 6 = staging + FAST stage A, 10 = + stage B, 2 = FAST without blur, 3 = product
+for m in 0 1 6 10 2 3; do
+  ORBFE_FAST_MODE=$m python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-match 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readlines()[-1]); print('mode $m', d['roofline']['stage_ms_per_step'])"
+done
