@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     __shared__ uint32_t sCand[kMaxTileCand];
     __shared__ uint32_t sCnt[4];  // tile: survivors, high survivors, pre-NMS low, pre-NMS high
     __shared__ uint32_t sBase;
-    __shared__ uint16_t sQA[kScH * kScW];  // stage queues (position indices)
+    __shared__ uint16_t sQA[kScH * kScW];  // stage queues; entry = sy << 7 | sx (score-map position), queue B adds the polarity in bits 13, 14
     __shared__ uint16_t sQB[kScH * kScW];
     __shared__ uint32_t sQ[2];
 
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     // evaluation on threads 0..67 (bit 9 of the mask).
     for (int e = tid; e < kScH * (kScPitch / 4); e += 256) reinterpret_cast<uint32_t*>(&sScore[0][0])[e] = 0;
     uint32_t passMask = 0;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, provably uniform -> scalar loop bounds
     const int syBeg = wv * 9 - (wv > 2 ? wv - 2 : 0);  // 0, 9, 18, 26
     const int syEnd = min(syBeg + (wv < 2 ? 9 : 8), kScH);
     {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         while (m) {
             const int b = __ffs(m) - 1;
             m &= m - 1;
-            const int e = b < 9 ? (syBeg + b) * kScW + lane : (tid >> 1) * kScW + kFastTW + (tid & 1);
+            const int e = b < 9 ? ((syBeg + b) << 7) | lane : ((tid >> 1) << 7) | (kFastTW + (tid & 1));
             sQA[base++] = (uint16_t)e;
         }
     }
@@ -384,13 +384,13 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             uint16_t e = 0;
             if (i < nA) {
                 e = sQA[i];
-                const int sy = e / kScW;
-                const int sx = e - sy * kScW;
+                const int sy = e >> 7;
+                const int sx = e & 127;
                 int d[16];
                 ring_diffs(sImg, sy + 3, sx + 3, d);
                 pol = segment_test(d, minTh);
             }
-            queue_push(pol != 0, (uint16_t)(e | (pol << 12)), sQB, &sQ[1], lane);  // e < 2244 < 4096
+            queue_push(pol != 0, (uint16_t)(e | (pol << 13)), sQB, &sQ[1], lane);  // e < 2^13
         }
     }
     __syncthreads();
@@ -398,12 +398,11 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int nB = (MODE & 8) ? 0 : (int)sQ[1];
     for (int i = tid; i < nB; i += 256) {
         const uint32_t q = sQB[i];
-        const int e = (int)(q & 0xfffu);
-        const int sy = e / kScW;
-        const int sx = e - sy * kScW;
+        const int sy = (int)((q >> 7) & 63u);
+        const int sx = (int)(q & 127u);
         int d[16];
         ring_diffs(sImg, sy + 3, sx + 3, d);
-        sScore[sy][sx] = (uint8_t)corner_score(d, (q & 0x1000u) != 0, (q & 0x2000u) != 0);
+        sScore[sy][sx] = (uint8_t)corner_score(d, (q & 0x2000u) != 0, (q & 0x4000u) != 0);
     }
     __syncthreads();
 
@@ -417,9 +416,9 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             bool pre = false, keep = false, hi = false;
             int ox = 0, oy = 0, s = 0;
             if (i < nB) {
-                const int e = (int)(sQB[i] & 0xfffu);
-                const int sy = e / kScW;
-                const int sx = e - sy * kScW;
+                const uint32_t q = sQB[i];
+                const int sy = (int)((q >> 7) & 63u);
+                const int sx = (int)(q & 127u);
                 ox = sx - 1;
                 oy = sy - 1;
                 pre = ox >= 0 && ox < kFastTW && oy >= 0 && oy < kFastTH;  // interior: counted once
