@@ -83,14 +83,28 @@ __device__ __forceinline__ void ring_diffs(const uint8_t (*img)[kImgW], int r, i
     d[15] = img[r + 3][c - 1] - v;
 }
 
-// stage B: full 16-pixel segment test at threshold th; bit 0 = bright 9-arc, bit 1 = dark 9-arc
-__device__ __forceinline__ uint32_t segment_test(const int (&d)[16], int th)
+// m = 2 * m + (a > b): the compare lands in VCC and v_addc shifts it in -- two instructions per ring bit
+// instead of compare + select + shift-or (the compiler has no pattern for this)
+__device__ __forceinline__ void shift_in_gt(uint32_t& m, int a, int b)
 {
+    asm("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+
+// stage B: full 16-pixel segment test at threshold th; bit 0 = bright 9-arc, bit 1 = dark 9-arc.
+// The ring masks are built most-significant-bit first (ring position 0 ends up in bit 15): a reversed
+// ring is still a ring, so the circular 9-run test is unchanged.
+__device__ __forceinline__ uint32_t segment_test(const uint8_t (*img)[kImgW], int r, int c, int th)
+{
+    const int v = img[r][c];
+    const int hiT = v + th, loT = v - th;
+    const int p[16] = {img[r + 3][c],     img[r + 3][c + 1], img[r + 2][c + 2], img[r + 1][c + 3], img[r][c + 3],     img[r - 1][c + 3],
+                       img[r - 2][c + 2], img[r - 3][c + 1], img[r - 3][c],     img[r - 3][c - 1], img[r - 2][c - 2], img[r - 1][c - 3],
+                       img[r][c - 3],     img[r + 1][c - 3], img[r + 2][c - 2], img[r + 3][c - 1]};
     uint32_t mb = 0, md = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        mb |= (uint32_t)(d[k] > th) << k;
-        md |= (uint32_t)(d[k] < -th) << k;
+        shift_in_gt(mb, p[k], hiT);  // p - v > th
+        shift_in_gt(md, loT, p[k]);  // p - v < -th
     }
     return (uint32_t)arc9(mb) | ((uint32_t)arc9(md) << 1);
 }
@@ -386,9 +400,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                 e = sQA[i];
                 const int sy = e >> 7;
                 const int sx = e & 127;
-                int d[16];
-                ring_diffs(sImg, sy + 3, sx + 3, d);
-                pol = segment_test(d, minTh);
+                pol = segment_test(sImg, sy + 3, sx + 3, minTh);
             }
             queue_push(pol != 0, (uint16_t)(e | (pol << 13)), sQB, &sQ[1], lane);  // e < 2^13
         }
