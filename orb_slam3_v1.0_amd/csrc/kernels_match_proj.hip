@@ -8,11 +8,16 @@
 // Exactness of the order-dependent parts:
 //  * The sequential "best / second best" scan (:92-104) returns the two smallest candidates under
 //    the total order (distance, visit position); the visit position of GetFeaturesInArea is (cell x,
-//    cell y, keypoint index).  That key is packed into one 64-bit word per candidate.
+//    cell y, keypoint index).  The keypoints of a frame are SORTED by that visit position once per call
+//    (their position in the sorted order is the "rank"), so a candidate key is one 32-bit word
+//    distance << 20 | rank.  The keypoints are STORED level-major, in visit order inside a level, with one
+//    cell-range table per level: the cells iy = minCY..maxCY of grid column ix at level l are one
+//    contiguous range, and a map point predicted at level L only walks levels L-1 and L (src/Frame.cc:437-452)
+//    -- <= 2 * (maxCX-minCX+1) short ranges instead of the whole frame.
 //  * The function is greedy: a keypoint already holding a map point with observations is skipped
-//    (:77-79), including points written earlier in the SAME loop.  Let claim[idx] = smallest index
-//    of an accepted map point (with observations) whose best match is idx.  Evaluating every map
-//    point i with "idx is free iff claim[idx] >= i", rebuilding claim[] from the results and
+//    (:77-79), including points written earlier in the SAME loop.  Let claim[rank] = smallest index
+//    of an accepted map point (with observations) whose best match is that keypoint.  Evaluating every
+//    map point i with "free iff claim >= i", rebuilding claim[] from the results and
 //    repeating until nothing changes reaches a fixed point, and by induction over i every fixed
 //    point equals the sequential result.  Map points are resolved in chunks of 1024 in index order,
 //    each chunk iterated to its own fixed point while all earlier chunks are already final.
@@ -20,12 +25,12 @@
 //    are still free; every candidate that was not stored is larger than all stored ones, so this is
 //    exact whenever two free entries are found or the list was not truncated.  When the list runs dry
 //    the verdict is often already implied by the last stored distance; otherwise the map point is
-//    rescanned exactly (one wave, LDS-resident frame, only the index range of its two levels).
+//    rescanned exactly (one wave over the rank range of its window columns, LDS-resident frame).
 //
 // Pipeline per call (B frames), all asynchronous on one stream, no host round trip:
-//   prep (grid cell per keypoint) -> top-K candidate keys per map point (thread per map point,
-//   keypoints + descriptors staged in LDS) -> ONE persistent block per frame resolves the claims
-//   (claim table in LDS) and writes the final matches.
+//   grid (cell per keypoint, sort by visit position, cell-range table) -> map points ordered by
+//   (level, tile) -> top-K candidate keys per map point (thread per map point) -> ONE persistent block
+//   per frame resolves the claims (claim table in LDS) and writes the final matches.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -42,7 +47,12 @@ namespace {
 constexpr int kClaimFree = 0x7fffffff;
 constexpr int kResolveThreads = 1024;
 constexpr int kTopK = 16;         // stored candidates per map point
-constexpr int kCandChunk = 512;   // keypoints staged in LDS per pass (48 B each -> 24 KB, 6 blocks per CU)
+constexpr uint32_t kKey32None = 0xffffffffu;
+constexpr int kRankBits = 20;
+constexpr uint32_t kRankMask = (1u << kRankBits) - 1u;
+constexpr int kSortLds = 2048;    // frames up to this many keypoints are sorted in LDS
+constexpr int kMaxCells = 1 << 22;          // grid cells (cols * rows)
+constexpr long long kMaxTableEntries = 1ll << 24;  // cells x levels: the cell-range tables take 4 B per entry per frame
 
 struct GridDesc {
     int cols, rows;
@@ -54,6 +64,7 @@ struct ProjArgs {
     GridDesc g;
     float th, thFar, nnRatio;
     int farPoints, bFactor;
+    int dCut;                     // candidates with distance >= dCut cannot change any verdict (see proj_dcut)
     const orbfe_keypoint* kp;     // [B][kpStride]
     const uint8_t* desc;          // [B][kpStride][32]
     const int* nKp;               // [B]
@@ -63,13 +74,20 @@ struct ProjArgs {
     const float* scaleFactors;    // [nLevels]
     int nLevels;
     // scratch
-    int* cellXY;                  // [B][kpStride] : cx | cy << 16, or -1
+    int sortCap;                  // pow2 >= kpStride (global sort path)
+    unsigned long long* sortKeys; // [B][sortCap] (only frames with more than kSortLds keypoints)
+    int* order;                   // [B][kpStride] rank -> keypoint index
+    uint8_t* octByRank;           // [B][kpStride] rank -> octave (clamped to 0..31)
+    int* rankOf;                  // [B][kpStride] keypoint index -> rank (global sort path only)
+    int4* rec;                    // [B][kpStride] per storage slot: {rank, octave | cell y << 8, x bits, y bits}
+    unsigned long long* descS;    // [B][kpStride][4] descriptors in storage order
+    int* colStart;                // [B][tabLevels][cols*rows + 1]: first storage slot of (level, cell v = cx*rows + cy)
+    int tabLevels;                // min(nLevels, 32)
     int* cnt;                     // [B][M] number of candidates (dist < 256) per map point
-    unsigned long long* topk;     // [B][kTopK][M] sorted smallest keys (entry-major: coalesced per sweep)
-    int* claimG;                  // [B][kpStride] fallback claim table (n > kLdsClaims)
-    int* perm;                    // [B][M] map points ordered by pyramid level (work assignment of the top-K pass)
-    int* dbg;                     // [B][4] diagnostics: sweeps, cooperative rescans, chunks, -
-    int* lvlStart;                // [B][34] first keypoint index per level (level-major input), [33] = sorted flag
+    uint32_t* topk;               // [B][kTopK][M] sorted smallest keys (entry-major: coalesced per sweep)
+    int* claimG;                  // [B][kpStride] fallback claim table (frames that do not fit the LDS image)
+    int* perm;                    // [B][M] map points ordered by (level, tile): work assignment of the top-K pass
+    int* dbg;                     // [B][4] diagnostics: sweeps, cooperative rescans, -, -
     int* matchOut;                // [B][kpStride]
     int* nMatches;                // [B]
 };
@@ -107,53 +125,145 @@ __device__ __forceinline__ MpWindow mp_window(const ProjArgs& A, const orbfe_map
     return w;
 }
 
-// candidate test of GetFeaturesInArea for a keypoint in grid cell `cell` (cx | cy << 16, -1 = none)
-__device__ __forceinline__ bool in_window(const MpWindow& w, int cell, float kx, float ky, int oct)
+// the part of GetFeaturesInArea's candidate test that the cell range does not already imply:
+// pyramid level (src/Frame.cc:437-452) and the square window (:457-461)
+__device__ __forceinline__ bool level_and_box(const MpWindow& w, float kx, float ky, int oct)
 {
-    if (cell < 0) return false;
-    const int cx = cell & 0xffff, cy = cell >> 16;
-    if (cx < w.minCX || cx > w.maxCX || cy < w.minCY || cy > w.maxCY) return false;
     const bool checkLevels = (w.minLevel > 0) || (w.maxLevel >= 0);  // src/Frame.cc:437
     if (checkLevels && (oct < w.minLevel || (w.maxLevel >= 0 && oct > w.maxLevel))) return false;
     const float dx = kx - w.x, dy = ky - w.y;
     return fabsf(dx) < w.r && fabsf(dy) < w.r;  // src/Frame.cc:461
 }
 
-// (distance, cell x, cell y, index): total order == visit order of the reference
-__device__ __forceinline__ unsigned long long make_key(int dist, int cell, int idx)
+__device__ __forceinline__ uint32_t make_key32(int dist, int rank) { return ((uint32_t)dist << kRankBits) | (uint32_t)rank; }
+
+// ---------------------------------------------------------------------------------------------
+// grid: Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480) + visit-order sort.
+// PosInGrid rounds and validates only the LINEAR index, so a keypoint with posX == cols lands in
+// column 0 of the next row.  One block per frame: 64-bit keys (visit cell v = cx * rows + cy) << 20 | index
+// are bitonic-sorted (LDS for frames up to kSortLds keypoints, else in global scratch); keypoints outside
+// the grid get v = cols*rows and sort to the end, where no window ever looks.
+// ---------------------------------------------------------------------------------------------
+template <bool LDS, class KeyFn>
+__device__ __forceinline__ void block_sort_keys(unsigned long long* sKeys, unsigned long long* gKeys, int n, int P, int tid, KeyFn keyOf)
 {
-    return ((unsigned long long)dist << 52) | ((unsigned long long)(cell & 0xffff) << 36) |
-           ((unsigned long long)(cell >> 16) << 20) | (unsigned long long)idx;
+    for (int j = tid; j < P; j += 1024) {
+        const unsigned long long key = j < n ? keyOf(j) : ~0ull;
+        if constexpr (LDS) sKeys[j] = key;
+        else gKeys[j] = key;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));
+                const int hi = lo | j2;
+                const bool up = (lo & k2) == 0;
+                unsigned long long a, b;
+                if constexpr (LDS) { a = sKeys[lo]; b = sKeys[hi]; }
+                else { a = gKeys[lo]; b = gKeys[hi]; }
+                if ((a > b) == up) {
+                    if constexpr (LDS) { sKeys[lo] = b; sKeys[hi] = a; }
+                    else { gKeys[lo] = b; gKeys[hi] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
-// Frame::PosInGrid (src/Frame.cc:470-480): round(), only the LINEAR index is validated, so a
-// keypoint with posX == cols lands in column 0 of the next row.
-__global__ void proj_prep_kernel(ProjArgs A)
+constexpr int kCellBits = 22;  // kMaxCells
+
+template <bool LDS>
+__global__ __launch_bounds__(1024) void proj_grid_kernel(ProjArgs A)
 {
-    const int f = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = A.nKp[f];
-    if (i >= A.kpStride) return;
-    int cell = -1;
-    if (i < n) {
-        const orbfe_keypoint& k = A.kp[(size_t)f * A.kpStride + i];
+    __shared__ unsigned long long sKeys[LDS ? kSortLds : 1];
+    __shared__ int sRankOf[LDS ? kSortLds : 1];
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = min(A.nKp[f], A.kpStride);
+    const int nCells = A.g.cols * A.g.rows;
+    const orbfe_keypoint* kp = A.kp + (size_t)f * A.kpStride;
+    unsigned long long* gKeys = A.sortKeys + (size_t)f * A.sortCap;
+    int* gRankOf = A.rankOf + (size_t)f * A.kpStride;
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int j = tid; j < A.kpStride; j += 1024) A.matchOut[(size_t)f * A.kpStride + j] = -1;
+    auto cellOf = [&](int j) {
+        const orbfe_keypoint& k = kp[j];
         float px = k.x - A.g.minX;
         px = px * A.g.invW;
         float py = k.y - A.g.minY;
         py = py * A.g.invH;
         const int posX = (int)roundf(px), posY = (int)roundf(py);
         const int lin = posY * A.g.cols + posX;
-        if (lin >= 0 && lin < A.g.cols * A.g.rows) cell = (lin % A.g.cols) | ((lin / A.g.cols) << 16);
+        int v = nCells;
+        if (lin >= 0 && lin < nCells) v = (lin % A.g.cols) * A.g.rows + lin / A.g.cols;
+        return v;
+    };
+    // sort 1: visit order (cell x, cell y, index) -> rank
+    block_sort_keys<LDS>(sKeys, gKeys, n, P, tid,
+                         [&](int j) { return ((unsigned long long)cellOf(j) << kRankBits) | (unsigned long long)j; });
+    for (int r = tid; r < n; r += 1024) {
+        unsigned long long key;
+        if constexpr (LDS) key = sKeys[r];
+        else key = gKeys[r];
+        const int idx = (int)(key & kRankMask);
+        A.order[(size_t)f * A.kpStride + r] = idx;
+        A.octByRank[(size_t)f * A.kpStride + r] = (uint8_t)min(max(kp[idx].octave, 0), 31);
+        if constexpr (LDS) sRankOf[idx] = r;
+        else gRankOf[idx] = r;
     }
-    A.cellXY[(size_t)f * A.kpStride + i] = cell;
-    A.matchOut[(size_t)f * A.kpStride + i] = -1;
+    __syncthreads();
+    // sort 2: storage order (level, cell x, cell y, index)
+    block_sort_keys<LDS>(sKeys, gKeys, n, P, tid, [&](int j) {
+        const unsigned long long lvl = (unsigned long long)min(max(kp[j].octave, 0), 31);
+        return (lvl << (kRankBits + kCellBits + 1)) | ((unsigned long long)cellOf(j) << kRankBits) | (unsigned long long)j;
+    });
+    const unsigned long long* desc = reinterpret_cast<const unsigned long long*>(A.desc + (size_t)f * A.kpStride * 32);
+    for (int p = tid; p < n; p += 1024) {
+        unsigned long long key;
+        if constexpr (LDS) key = sKeys[p];
+        else key = gKeys[p];
+        const int idx = (int)(key & kRankMask);
+        const int v = (int)((key >> kRankBits) & ((1u << (kCellBits + 1)) - 1u));
+        const int lvl = (int)(key >> (kRankBits + kCellBits + 1));
+        const orbfe_keypoint k = kp[idx];
+        int rank;
+        if constexpr (LDS) rank = sRankOf[idx];
+        else rank = gRankOf[idx];
+        const int cy = v < nCells ? v % A.g.rows : 0x7fff;
+        A.rec[(size_t)f * A.kpStride + p] = make_int4(rank, lvl | (cy << 8), __float_as_int(k.x), __float_as_int(k.y));
+        unsigned long long* dd = A.descS + ((size_t)f * A.kpStride + p) * 4;
+        dd[0] = desc[(size_t)idx * 4 + 0];
+        dd[1] = desc[(size_t)idx * 4 + 1];
+        dd[2] = desc[(size_t)idx * 4 + 2];
+        dd[3] = desc[(size_t)idx * 4 + 3];
+    }
+    // colStart[l][v] = first storage slot whose (level, cell) is >= (l, v) (lower bound), v = 0..nCells
+    int* cs = A.colStart + (size_t)f * A.tabLevels * (nCells + 1);
+    const int nTab = A.tabLevels * (nCells + 1);
+    for (int e = tid; e < nTab; e += 1024) {
+        const int l = e / (nCells + 1);
+        const int v = e - l * (nCells + 1);
+        const unsigned long long want = ((unsigned long long)l << (kCellBits + 1)) | (unsigned long long)v;
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            unsigned long long key;
+            if constexpr (LDS) key = sKeys[mid];
+            else key = gKeys[mid];
+            if ((key >> kRankBits) < want) lo = mid + 1;
+            else hi = mid;
+        }
+        cs[e] = lo;
+    }
 }
 
 // Counting sort of a frame's map points by (pyramid level, 8 x 6 spatial tile); the last bucket
 // holds the invalid ones.  Only the WORK ASSIGNMENT of the top-K pass uses this order: the 64 lanes
-// of a wave then search the same levels in overlapping windows, so a keypoint is relevant either
-// for most lanes or for none and the whole wave skips it.  Results stay indexed by the original
-// map point order.
+// of a wave then walk windows of similar size in the same part of the frame (similar trip counts,
+// shared cache lines).  Results stay indexed by the original map point order.
 constexpr int kTilesX = 8, kTilesY = 6;
 constexpr int kSortBuckets = 32 * kTilesX * kTilesY + 1;
 
@@ -191,180 +301,182 @@ __global__ __launch_bounds__(1024) void proj_sort_kernel(ProjArgs A)
         const int pos = atomicAdd(&sHist[sort_bucket(A, mps[i])], 1);
         A.perm[(size_t)f * A.M + pos] = i;
     }
-
-    // Keypoint index range per pyramid level.  The extractor emits keypoints level-major
-    // (src/ORBextractor.cc:499-500); when that holds, lvlStart[l] = first index with octave >= l and a
-    // block of the top-K pass only walks the levels its map points can match.  For any other order
-    // lvlStart[33] = 0 ("not sorted") and the pass walks everything.
-    __shared__ int sStart[34];
-    __syncthreads();
-    const int n = A.nKp[f];
-    const orbfe_keypoint* kp = A.kp + (size_t)f * A.kpStride;
-    if (tid < 33) sStart[tid] = n;
-    if (tid == 33) sStart[33] = 1;
-    __syncthreads();
-    for (int j = tid; j < n; j += 1024) {
-        const int o = min(max(kp[j].octave, 0), 32);
-        atomicMin(&sStart[o], j);
-        if (j + 1 < n && kp[j + 1].octave < kp[j].octave) sStart[33] = 0;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int l2 = 31; l2 >= 0; l2--) sStart[l2] = min(sStart[l2], sStart[l2 + 1]);
-        for (int l2 = 0; l2 < 34; l2++) A.lvlStart[f * 34 + l2] = sStart[l2];
-    }
 }
 
-// Thread per map point; a block owns 256 map points of one frame and stages the frame's keypoints
-// (cell, x, y, octave, descriptor) in LDS in chunks, so the inner loop never waits on global memory.
-// Every lane looks at the same keypoint at the same time -> LDS broadcast reads.
-__global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
+// Thread per map point: walk the storage range of every (level, grid column) of the window (cells
+// minCY..maxCY of one column are contiguous), keep the kTopK smallest keys sorted (min/max network on
+// 32-bit keys).  A block owns 256 map points of one frame, ordered by (level, tile): the storage segment
+// of the levels they can match is staged in LDS (records + descriptors, 48 B per keypoint), because the
+// per-lane gathers of this loop are ~8x cheaper from LDS than through the vector L1.
+constexpr int kTopkLds = 1024;  // staged keypoints per block (48 KB -> 3 blocks per CU); larger segments read global memory
+
+struct TopkLds {
+    int4 rec[kTopkLds];
+    unsigned long long desc[kTopkLds][4];
+};
+
+template <bool LDS>
+__device__ __forceinline__ int topk_scan(const ProjArgs& A, const MpWindow& w, const int* cs, int tabStride, const int4* rec,
+                                         const unsigned long long* descS, const TopkLds* S, int segBase,
+                                         unsigned long long d0, unsigned long long d1, unsigned long long d2,
+                                         unsigned long long d3, uint32_t (&keys)[kTopK])
 {
-    __shared__ int4 sKp[kCandChunk];  // {cell, octave, x bits, y bits}: one ds_read_b128 per keypoint
-    __shared__ unsigned long long sDesc[kCandChunk][4];
-    const int f = blockIdx.y;
-    const int slotIdx = blockIdx.x * 256 + threadIdx.x;
-    const bool live = slotIdx < A.M;
-    const int i = live ? A.perm[(size_t)f * A.M + slotIdx] : 0;  // level-coherent waves
-    const int n = A.nKp[f];
-    const orbfe_keypoint* kp = A.kp + (size_t)f * A.kpStride;
-    const int* cellXY = A.cellXY + (size_t)f * A.kpStride;
-    const unsigned long long* desc = reinterpret_cast<const unsigned long long*>(A.desc + (size_t)f * A.kpStride * 32);
-    MpWindow w;
-    w.valid = false;
-    w.minLevel = w.maxLevel = 0;
-    if (live) w = mp_window(A, A.mps[(size_t)f * A.M + i]);
-    unsigned long long d4[4] = {0, 0, 0, 0};
-    if (live && w.valid) {
-        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * A.M + i) * 32);
-        d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
-    }
-    unsigned long long keys[kTopK];
-#pragma unroll
-    for (int t = 0; t < kTopK; t++) keys[t] = kKeyNone;
     int total = 0;
-    // keypoint index range this block has to look at: the levels [min(lvl)-1, max(lvl)] of its map points
-    __shared__ int sLvlLo, sLvlHi;
-    if (threadIdx.x == 0) { sLvlLo = 64; sLvlHi = -1; }
-    __syncthreads();
-    if (w.valid) {
-        atomicMin(&sLvlLo, w.minLevel);
-        atomicMax(&sLvlHi, w.maxLevel);
-    }
-    __syncthreads();
-    int jlo = 0, jhi = n;
-    {
-        const int* ls = A.lvlStart + f * 34;
-        if (sLvlHi < 0) jhi = 0;  // no valid map point in this block
-        else if (ls[33]) {        // level-major keypoints
-            jlo = ls[min(max(sLvlLo, 0), 32)];
-            jhi = ls[min(sLvlHi + 1, 32)];
-        }
-    }
-    for (int base = jlo; base < jhi; base += kCandChunk) {
-        const int m = min(kCandChunk, jhi - base);
-        __syncthreads();
-        for (int j = threadIdx.x; j < m; j += 256) {
-            const orbfe_keypoint k = kp[base + j];
-            sKp[j] = make_int4(cellXY[base + j], k.octave, __float_as_int(k.x), __float_as_int(k.y));
-        }
-        for (int j = threadIdx.x; j < m * 4; j += 256) sDesc[0][j] = desc[(size_t)base * 4 + j];
-        __syncthreads();
-        if (w.valid) {
-            const bool checkLevels = (w.minLevel > 0) || (w.maxLevel >= 0);  // src/Frame.cc:437
-            for (int j = 0; j < m; j++) {
-                const int4 kq = sKp[j];  // broadcast read
-                const int cell = kq.x, oct = kq.y;
-                // level filter first: waves are level-coherent, so most keypoints fail for all 64 lanes
-                if (checkLevels && (oct < w.minLevel || (w.maxLevel >= 0 && oct > w.maxLevel))) continue;
-                if (!in_window(w, cell, __int_as_float(kq.z), __int_as_float(kq.w), oct)) continue;
-                const int dist = __popcll(sDesc[j][0] ^ d4[0]) + __popcll(sDesc[j][1] ^ d4[1]) +
-                                 __popcll(sDesc[j][2] ^ d4[2]) + __popcll(sDesc[j][3] ^ d4[3]);
-                if (dist >= 256) continue;  // can enter neither slot (the reference's bests start at 256)
+    const int rows = A.g.rows;
+    for (int l = max(w.minLevel, 0); l <= w.maxLevel; l++) {  // levels that pass src/Frame.cc:437-452
+        const int* csl = cs + (size_t)l * tabStride;
+        for (int cx = w.minCX; cx <= w.maxCX; cx++) {
+            const int s = csl[cx * rows + w.minCY], e = csl[cx * rows + w.maxCY + 1];
+            for (int p = s; p < e; p++) {
+                int4 q;
+                if constexpr (LDS) q = S->rec[p - segBase];
+                else q = rec[p];
+                const float dx = __int_as_float(q.z) - w.x, dy = __int_as_float(q.w) - w.y;
+                if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;  // src/Frame.cc:461
+                int dist;
+                if constexpr (LDS) {
+                    const unsigned long long* kd = S->desc[p - segBase];
+                    dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
+                } else {
+                    const unsigned long long* kd = descS + (size_t)p * 4;
+                    dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
+                }
+                if (dist >= A.dCut) continue;  // cannot change the verdict (proj_dcut)
                 total++;
-                unsigned long long key = make_key(dist, cell, base + j);
+                uint32_t key = make_key32(dist, q.x);
                 if (key < keys[kTopK - 1]) {  // sorted insert
 #pragma unroll
                     for (int t = 0; t < kTopK; t++) {
-                        const unsigned long long lo = key < keys[t] ? key : keys[t];
-                        key = key < keys[t] ? keys[t] : key;
+                        const uint32_t lo = min(key, keys[t]);
+                        key = max(key, keys[t]);
                         keys[t] = lo;
                     }
                 }
             }
         }
     }
-    if (live) {
-        A.cnt[(size_t)f * A.M + i] = total;
-#pragma unroll
-        for (int t = 0; t < kTopK; t++) A.topk[((size_t)f * kTopK + t) * A.M + i] = keys[t];
+    return total;
+}
+
+__global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
+{
+    __shared__ TopkLds S;
+    __shared__ int sLvlLo, sLvlHi;
+    const int f = blockIdx.y;
+    const int slotIdx = blockIdx.x * 256 + threadIdx.x;
+    const bool live = slotIdx < A.M;
+    const int i = live ? A.perm[(size_t)f * A.M + slotIdx] : 0;
+    MpWindow w;
+    w.valid = false;
+    w.minLevel = w.maxLevel = 0;
+    if (live) w = mp_window(A, A.mps[(size_t)f * A.M + i]);
+    if (threadIdx.x == 0) { sLvlLo = 64; sLvlHi = -1; }
+    __syncthreads();
+    if (w.valid) {
+        atomicMin(&sLvlLo, max(w.minLevel, 0));
+        atomicMax(&sLvlHi, w.maxLevel);
     }
+    __syncthreads();
+    const int tabStride = A.g.cols * A.g.rows + 1;
+    const int* cs = A.colStart + (size_t)f * A.tabLevels * tabStride;
+    const int4* rec = A.rec + (size_t)f * A.kpStride;
+    const unsigned long long* descS = A.descS + (size_t)f * A.kpStride * 4;
+    // storage segment of the levels this block can match: [first slot of level lo, first slot of level hi+1)
+    int segBase = 0, segEnd = 0;
+    if (sLvlHi >= 0) {
+        segBase = cs[(size_t)sLvlLo * tabStride];
+        segEnd = sLvlHi + 1 < A.tabLevels ? cs[(size_t)(sLvlHi + 1) * tabStride] : min(A.nKp[f], A.kpStride);
+    }
+    const bool useLds = segEnd - segBase <= kTopkLds;  // block-uniform
+    if (useLds) {
+        for (int j = threadIdx.x; j < segEnd - segBase; j += 256) S.rec[j] = rec[segBase + j];
+        for (int j = threadIdx.x; j < (segEnd - segBase) * 4; j += 256) S.desc[0][j] = descS[(size_t)segBase * 4 + j];
+    }
+    __syncthreads();
+    if (!live) return;
+    uint32_t keys[kTopK];
+#pragma unroll
+    for (int t = 0; t < kTopK; t++) keys[t] = kKey32None;
+    int total = 0;
+    if (w.valid) {
+        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * A.M + i) * 32);
+        const unsigned long long d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
+        if (useLds) total = topk_scan<true>(A, w, cs, tabStride, rec, descS, &S, segBase, d0, d1, d2, d3, keys);
+        else total = topk_scan<false>(A, w, cs, tabStride, rec, descS, &S, segBase, d0, d1, d2, d3, keys);
+    }
+    A.cnt[(size_t)f * A.M + i] = total;
+#pragma unroll
+    for (int t = 0; t < kTopK; t++) A.topk[((size_t)f * kTopK + t) * A.M + i] = keys[t];
 }
 
 // One persistent block per frame, one THREAD per map point, chunks of 1024 map points in index order.
-// The frame's keypoints (cell, octave, x, y) and descriptors are staged in LDS once (frames up to
-// kResN keypoints), so sweeps and the exact rescans of starved map points never touch global memory.
+// The frame's keypoints (cell, octave, x, y) and descriptors, in rank order, are staged in LDS once (frames
+// up to kResN keypoints), so sweeps and the exact rescans of starved map points never touch global memory.
 constexpr int kResN = 2048;
 
 struct ResolveLds {
-    int claim[kResN];
-    int4 kp[kResN];                       // {cell, octave, x bits, y bits}
-    unsigned long long desc[kResN][4];
+    int claim[kResN];                     // by rank
+    uint8_t oct[kResN];                   // by rank
+    int4 rec[kResN];                      // by storage slot: {rank, octave | cell y << 8, x bits, y bits}
+    unsigned long long desc[kResN][4];    // by storage slot
 };
 
-// exact rescan for a map point whose stored top-K ran dry: one WAVE scans all keypoints of the
-// frame (lane-strided) and reduces the two smallest free keys; all lanes get the result.
+__device__ __forceinline__ void wave_top2_u32(uint32_t& k1, uint32_t& k2)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o1 = __shfl_xor(k1, d), o2 = __shfl_xor(k2, d);
+        const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+        k2 = min(hi, min(k2, o2));
+        k1 = lo;
+    }
+}
+
+// exact rescan for a map point whose stored top-K ran dry: one WAVE scans the contiguous rank range of the
+// window's grid columns (lane-strided) and reduces the two smallest free keys; all lanes get the result.
 // The claim test goes first: a starved map point sits in a region where nearly everything is taken.
 template <bool LDS>
 __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, int i, const int* claim,
-                                                    const ResolveLds* S, int lane, unsigned long long& k1,
-                                                    unsigned long long& k2)
+                                                    const ResolveLds* S, int lane, uint32_t& k1, uint32_t& k2)
 {
     const MpWindow w = mp_window(A, A.mps[(size_t)f * A.M + i]);
-    k1 = kKeyNone;
-    k2 = kKeyNone;
+    k1 = kKey32None;
+    k2 = kKey32None;
     if (w.valid) {  // wave-uniform
-        const int n = A.nKp[f];
-        const orbfe_keypoint* kp = A.kp + (size_t)f * A.kpStride;
-        const int* cellXY = A.cellXY + (size_t)f * A.kpStride;
-        const uint8_t* desc = A.desc + (size_t)f * A.kpStride * 32;
+        const int rows = A.g.rows;
+        const int tabStride = A.g.cols * rows + 1;
+        const int* cs = A.colStart + (size_t)f * A.tabLevels * tabStride;
+        const int4* rec = A.rec + (size_t)f * A.kpStride;
+        const unsigned long long* descS = A.descS + (size_t)f * A.kpStride * 4;
         unsigned long long d4[4];
         const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * A.M + i) * 32);
         d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
-        // level-major keypoints: only the index range of levels [minLevel, maxLevel] can pass the filter
-        int jlo = 0, jhi = n;
-        {
-            const int* ls = A.lvlStart + f * 34;
-            if (ls[33]) {
-                jlo = ls[min(max(w.minLevel, 0), 32)];
-                jhi = ls[min(max(w.maxLevel, -1) + 1, 32)];
+        for (int l = max(w.minLevel, 0); l <= w.maxLevel; l++) {
+            const int* csl = cs + (size_t)l * tabStride;
+            const int plo = csl[w.minCX * rows], phi = csl[(w.maxCX + 1) * rows];  // all rows of the window's columns
+            for (int p = plo + lane; p < phi; p += 64) {
+                int4 q;
+                if constexpr (LDS) q = S->rec[p];
+                else q = rec[p];
+                if (claim[q.x] < i) continue;
+                const int cy = q.y >> 8;
+                if (cy < w.minCY || cy > w.maxCY) continue;
+                const float dx = __int_as_float(q.z) - w.x, dy = __int_as_float(q.w) - w.y;
+                if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;
+                int dist;
+                if constexpr (LDS)
+                    dist = __popcll(S->desc[p][0] ^ d4[0]) + __popcll(S->desc[p][1] ^ d4[1]) +
+                           __popcll(S->desc[p][2] ^ d4[2]) + __popcll(S->desc[p][3] ^ d4[3]);
+                else
+                    dist = hamming256(reinterpret_cast<const uint2*>(descS + (size_t)p * 4), d4);
+                if (dist >= A.dCut) continue;
+                const uint32_t key = make_key32(dist, q.x);
+                if (key < k1) { k2 = k1; k1 = key; }
+                else if (key < k2) k2 = key;
             }
-        }
-        for (int idx = jlo + lane; idx < jhi; idx += 64) {
-            if (claim[idx] < i) continue;
-            int cell, oct, dist;
-            float kx, ky;
-            if (LDS) {
-                const int4 q = S->kp[idx];
-                cell = q.x; oct = q.y; kx = __int_as_float(q.z); ky = __int_as_float(q.w);
-            } else {
-                cell = cellXY[idx];
-                const orbfe_keypoint k = kp[idx];
-                oct = k.octave; kx = k.x; ky = k.y;
-            }
-            if (!in_window(w, cell, kx, ky, oct)) continue;
-            if (LDS)
-                dist = __popcll(S->desc[idx][0] ^ d4[0]) + __popcll(S->desc[idx][1] ^ d4[1]) +
-                       __popcll(S->desc[idx][2] ^ d4[2]) + __popcll(S->desc[idx][3] ^ d4[3]);
-            else
-                dist = hamming256(reinterpret_cast<const uint2*>(desc + (size_t)idx * 32), d4);
-            if (dist >= 256) continue;
-            const unsigned long long key = make_key(dist, cell, idx);
-            if (key < k1) { k2 = k1; k1 = key; }
-            else if (key < k2) k2 = key;
         }
     }
-    wave_top2(k1, k2);
+    wave_top2_u32(k1, k2);
 }
 
 template <bool LDS>
@@ -375,27 +487,28 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
     __shared__ int sCount;
     __shared__ int sFbCount;                             // starved map points of the current sweep
     __shared__ int sFbMp[kResolveThreads];
-    __shared__ unsigned long long sFbK1[kResolveThreads], sFbK2[kResolveThreads];
+    __shared__ uint32_t sFbK1[kResolveThreads], sFbK2[kResolveThreads];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
-    const int n = A.nKp[f];
+    const int n = min(A.nKp[f], A.kpStride);
     const int M = A.M;
     int* claim = LDS ? S.claim : A.claimG + (size_t)f * A.kpStride;
     const orbfe_map_point* mps = A.mps + (size_t)f * M;
-    const orbfe_keypoint* kp = A.kp + (size_t)f * A.kpStride;
+    const int* order = A.order + (size_t)f * A.kpStride;
+    const int4* rec = A.rec + (size_t)f * A.kpStride;
     const int* initObs = A.initObs ? A.initObs + (size_t)f * A.kpStride : nullptr;
 
-    // claim[idx] = -1 if the slot holds a map point with observations on entry (:77-79); later the
-    // smallest accepted map point (with observations) whose best match is idx
-    for (int i = tid; i < n; i += kResolveThreads) claim[i] = (initObs && initObs[i] > 0) ? -1 : kClaimFree;
-    if (LDS) {
-        const int* cellXY = A.cellXY + (size_t)f * A.kpStride;
-        const unsigned long long* desc = reinterpret_cast<const unsigned long long*>(A.desc + (size_t)f * A.kpStride * 32);
-        for (int j = tid; j < n; j += kResolveThreads) {
-            const orbfe_keypoint k = kp[j];
-            S.kp[j] = make_int4(cellXY[j], k.octave, __float_as_int(k.x), __float_as_int(k.y));
+    // claim[rank] = -1 if the slot holds a map point with observations on entry (:77-79); later the
+    // smallest accepted map point (with observations) whose best match is that keypoint
+    for (int r = tid; r < n; r += kResolveThreads) claim[r] = (initObs && initObs[order[r]] > 0) ? -1 : kClaimFree;
+    const uint8_t* octByRank = A.octByRank + (size_t)f * A.kpStride;
+    if constexpr (LDS) {
+        const unsigned long long* descS = A.descS + (size_t)f * A.kpStride * 4;
+        for (int r = tid; r < n; r += kResolveThreads) {
+            S.rec[r] = rec[r];
+            S.oct[r] = octByRank[r];
         }
-        for (int j = tid; j < n * 4; j += kResolveThreads) S.desc[0][j] = desc[j];
+        for (int j = tid; j < n * 4; j += kResolveThreads) S.desc[0][j] = descS[j];
     }
     if (tid == 0) sCount = 0;
     int nAccepted = 0;
@@ -404,9 +517,9 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
         const int i = chunk + tid;
         const bool live = i < M;
         int c = 0, obs = 0;
-        unsigned long long keys[kTopK];
+        uint32_t keys[kTopK];
 #pragma unroll
-        for (int t = 0; t < kTopK; t++) keys[t] = kKeyNone;
+        for (int t = 0; t < kTopK; t++) keys[t] = kKey32None;
         if (live) {
             c = A.cnt[(size_t)f * M + i];
             obs = mps[i].observations;
@@ -415,7 +528,7 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
                 for (int t = 0; t < kTopK; t++) keys[t] = A.topk[((size_t)f * kTopK + t) * M + i];
             }
         }
-        int res = -1;
+        int res = -1;  // rank of the accepted keypoint
         for (int iter = 0; iter <= kResolveThreads + 1; iter++) {
             __syncthreads();
             // drop the tentative claims of this chunk (entries >= chunk), keep earlier chunks' final ones
@@ -426,28 +539,28 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
             if (res >= 0 && obs > 0) atomicMin(&claim[res], i);
             __syncthreads();
             int result = -1;
-            unsigned long long k1 = kKeyNone, k2 = kKeyNone;
+            uint32_t k1 = kKey32None, k2 = kKey32None;
             int slot = -1;
             if (c > 0) {
 #pragma unroll
                 for (int t = 0; t < kTopK; t++) {  // ascending: the first two free entries are the answer
-                    const unsigned long long key = keys[t];
-                    if (key != kKeyNone && claim[(int)(key & 0xFFFFF)] >= i) {
-                        if (k1 == kKeyNone) k1 = key;
-                        else if (k2 == kKeyNone) k2 = key;
+                    const uint32_t key = keys[t];
+                    if (key != kKey32None && claim[(int)(key & kRankMask)] >= i) {
+                        if (k1 == kKey32None) k1 = key;
+                        else if (k2 == kKey32None) k2 = key;
                     }
                 }
-                if (k2 == kKeyNone && c > kTopK) {
+                if (k2 == kKey32None && c > kTopK) {
                     // The stored list ran dry.  Every candidate that was not stored has a key above
                     // keys[K-1], i.e. a distance >= dK.  Two cases are decided without looking at them:
                     //  - nothing free and dK > TH_HIGH: the best free candidate fails :108 -> no match;
                     //  - one free entry with best <= nnRatio * dK: the ratio test :110 cannot reject
                     //    (the float product is monotone in the unknown second distance >= dK).
-                    const int dK = (int)(keys[kTopK - 1] >> 52);
+                    const int dK = (int)(keys[kTopK - 1] >> kRankBits);
                     bool decided = false;
-                    if (k1 == kKeyNone) decided = dK > ORBFE_TH_HIGH;
+                    if (k1 == kKey32None) decided = dK > ORBFE_TH_HIGH;
                     else {
-                        const int bd = (int)(k1 >> 52);
+                        const int bd = (int)(k1 >> kRankBits);
                         decided = bd > ORBFE_TH_HIGH || (A.nnRatio > 0.f && !((float)bd > A.nnRatio * (float)dK));
                         if (decided) k2 = keys[kTopK - 1];  // stand-in with distance dK: same verdict as the true second
                     }
@@ -462,25 +575,28 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
             {
                 const int nFb = sFbCount;
                 for (int q = tid >> 6; q < nFb; q += kResolveThreads / 64) {  // one wave per starved map point
-                    unsigned long long a1, a2;
+                    uint32_t a1, a2;
                     full_scan_top2_wave<LDS>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
                     if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
                 }
             }
             __syncthreads();
             if (slot >= 0) { k1 = sFbK1[slot]; k2 = sFbK2[slot]; }
-            if (k1 != kKeyNone) {
-                const int bestDist = (int)(k1 >> 52), bestIdx = (int)(k1 & 0xFFFFF);
-                const int bestLevel = LDS ? S.kp[bestIdx].y : kp[bestIdx].octave;
+            if (k1 != kKey32None) {
+                const int bestDist = (int)(k1 >> kRankBits), bestRank = (int)(k1 & kRankMask);
+                int bestLevel;
+                if constexpr (LDS) bestLevel = S.oct[bestRank];
+                else bestLevel = octByRank[bestRank];
                 int bestDist2 = 256, bestLevel2 = -1;
-                if (k2 != kKeyNone) {
-                    bestDist2 = (int)(k2 >> 52);
-                    const int i2 = (int)(k2 & 0xFFFFF);
-                    bestLevel2 = LDS ? S.kp[i2].y : kp[i2].octave;
+                if (k2 != kKey32None) {
+                    bestDist2 = (int)(k2 >> kRankBits);
+                    const int r2 = (int)(k2 & kRankMask);
+                    if constexpr (LDS) bestLevel2 = S.oct[r2];
+                    else bestLevel2 = octByRank[r2];
                 }
                 if (bestDist <= ORBFE_TH_HIGH) {  // :108-117
                     const bool reject = bestLevel == bestLevel2 && (float)bestDist > A.nnRatio * (float)bestDist2;
-                    if (!reject) result = bestIdx;
+                    if (!reject) result = bestRank;
                 }
             }
             if (result != res) {
@@ -493,7 +609,7 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
         }
         // F->mvpMapPoints[bestIdx] = pMP in map-point order: the last writer wins; nmatches counts accepts
         if (res >= 0) {
-            atomicMax(&A.matchOut[(size_t)f * A.kpStride + res], i);
+            atomicMax(&A.matchOut[(size_t)f * A.kpStride + order[res]], i);
             nAccepted++;
         }
     }
@@ -502,41 +618,76 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
     if (tid == 0) A.nMatches[f] = sCount;
 }
 
+// Distance cut-off.  The verdict of src/ORBmatcher.cc:108-117 only depends on candidates below a bound:
+// a best candidate needs dist <= TH_HIGH, and a second-best with nnRatio * d2 >= TH_HIGH can never reject a
+// best <= TH_HIGH (the float product is monotone in d2) -- it acts exactly like "no second candidate".
+// So every candidate with dist >= max(TH_HIGH + 1, min{d : !(TH_HIGH > nnRatio * d)}) is skipped: with
+// nnRatio 0.85 that is 118, which removes ~90 % of the unrelated keypoints (their distances cluster at 128)
+// from the sorted inserts and keeps the stored lists complete.
+int proj_dcut(float nnRatio)
+{
+    int D = 256;
+    for (int d = 0; d < 256; d++)
+        if (!((float)ORBFE_TH_HIGH > nnRatio * (float)d)) {
+            D = d;
+            break;
+        }
+    return std::max(D, ORBFE_TH_HIGH + 1);
+}
+
 // carve the device scratch after whatever `sc` already holds; sets A's scratch pointers
 int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::string& err)
 {
     const int B = A.B, M = A.M;
-    const size_t oCell = sc.take((size_t)B * A.kpStride * sizeof(int));
+    const size_t nCells = (size_t)A.g.cols * A.g.rows;
+    A.sortCap = 1;
+    while (A.sortCap < A.kpStride) A.sortCap <<= 1;
+    const bool ldsSort = A.kpStride <= kSortLds;
+    const size_t oKeys = sc.take(ldsSort ? 8 : (size_t)B * A.sortCap * sizeof(unsigned long long));
+    A.tabLevels = std::min(std::max(A.nLevels, 1), 32);
+    A.dCut = proj_dcut(A.nnRatio);
+    const size_t oOrder = sc.take((size_t)B * A.kpStride * sizeof(int));
+    const size_t oOct = sc.take((size_t)B * A.kpStride);
+    const size_t oRankOf = sc.take(ldsSort ? 8 : (size_t)B * A.kpStride * sizeof(int));
+    const size_t oRec = sc.take((size_t)B * A.kpStride * sizeof(int4));
+    const size_t oDescS = sc.take((size_t)B * A.kpStride * 32);
+    const size_t oCol = sc.take((size_t)B * A.tabLevels * (nCells + 1) * sizeof(int));
     const size_t oCnt = sc.take((size_t)B * std::max(M, 1) * sizeof(int));
-    const size_t oTopk = sc.take((size_t)B * kTopK * std::max(M, 1) * sizeof(unsigned long long));
+    const size_t oTopk = sc.take((size_t)B * kTopK * std::max(M, 1) * sizeof(uint32_t));
     const size_t oClaim = sc.take((size_t)B * A.kpStride * sizeof(int));
     const size_t oPerm = sc.take((size_t)B * std::max(M, 1) * sizeof(int));
     const size_t oDbg = sc.take((size_t)B * 4 * sizeof(int));
-    const size_t oLvl = sc.take((size_t)B * 34 * sizeof(int));
     int rc = ensure(m, sc.off, hostNeed + 256, err);
     if (rc != ORBFE_OK) return rc;
     uint8_t* dp = static_cast<uint8_t*>(m.d);
-    A.cellXY = reinterpret_cast<int*>(dp + oCell);
+    A.sortKeys = reinterpret_cast<unsigned long long*>(dp + oKeys);
+    A.order = reinterpret_cast<int*>(dp + oOrder);
+    A.octByRank = dp + oOct;
+    A.rankOf = reinterpret_cast<int*>(dp + oRankOf);
+    A.rec = reinterpret_cast<int4*>(dp + oRec);
+    A.descS = reinterpret_cast<unsigned long long*>(dp + oDescS);
+    A.colStart = reinterpret_cast<int*>(dp + oCol);
     A.cnt = reinterpret_cast<int*>(dp + oCnt);
-    A.topk = reinterpret_cast<unsigned long long*>(dp + oTopk);
+    A.topk = reinterpret_cast<uint32_t*>(dp + oTopk);
     A.claimG = reinterpret_cast<int*>(dp + oClaim);
     A.perm = reinterpret_cast<int*>(dp + oPerm);
     A.dbg = reinterpret_cast<int*>(dp + oDbg);
-    A.lvlStart = reinterpret_cast<int*>(dp + oLvl);
     return ORBFE_OK;
 }
 
 int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
 {
-    const dim3 blk(256);
-    hipLaunchKernelGGL(proj_prep_kernel, dim3((A.kpStride + 255) / 256, A.B), blk, 0, s, A);
+    if (A.kpStride <= kSortLds)
+        hipLaunchKernelGGL(proj_grid_kernel<true>, dim3(A.B), dim3(1024), 0, s, A);
+    else
+        hipLaunchKernelGGL(proj_grid_kernel<false>, dim3(A.B), dim3(1024), 0, s, A);
     if (A.M == 0) {
         MCHK(hipMemsetAsync(A.nMatches, 0, (size_t)A.B * sizeof(int), s));
         return ORBFE_OK;
     }
     MCHK(hipMemsetAsync(A.dbg, 0, (size_t)A.B * 4 * sizeof(int), s));
     hipLaunchKernelGGL(proj_sort_kernel, dim3(A.B), dim3(1024), 0, s, A);
-    hipLaunchKernelGGL(proj_topk_kernel, dim3((A.M + 255) / 256, A.B), blk, 0, s, A);
+    hipLaunchKernelGGL(proj_topk_kernel, dim3((A.M + 255) / 256, A.B), dim3(256), 0, s, A);
     if (A.kpStride <= kResN)  // nKp[f] <= kpStride: the whole frame fits the LDS image
         hipLaunchKernelGGL(proj_resolve_kernel<true>, dim3(A.B), dim3(kResolveThreads), 0, s, A);
     else
@@ -562,7 +713,10 @@ int match_projection_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view*
     for (int i = 0; i < n; i++) matchOut[i] = -1;
     *nMatches = 0;
     if (n == 0 || M == 0) return ORBFE_OK;
-    if (n >= (1 << 20) || F->grid_cols > 65535 || F->grid_rows > 32767 || F->n_levels < 1) return ORBFE_ERR_UNSUPPORTED;
+    if (n >= (1 << 20) || F->grid_cols > 65535 || F->grid_rows > 32767 || F->n_levels < 1 ||
+        (long long)F->grid_cols * F->grid_rows > kMaxCells ||
+        (long long)F->grid_cols * F->grid_rows * std::min(F->n_levels, 32) > kMaxTableEntries)
+        return ORBFE_ERR_UNSUPPORTED;
     for (int i = 0; i < M; i++)
         if (mps[i].in_view && (mps[i].level < 0 || mps[i].level >= F->n_levels)) return ORBFE_ERR_INVALID_ARG;
 
@@ -630,7 +784,9 @@ int match_projection_batch_device(MatchScratch& m, hipStream_t s, int B, const o
                                   int farPoints, float thFar, float nnRatio, int* dMatchOut, int* dNMatches,
                                   std::string& err)
 {
-    if (kpStride >= (1 << 20) || gridCols > 65535 || gridRows > 32767) return ORBFE_ERR_UNSUPPORTED;
+    if (kpStride >= (1 << 20) || gridCols > 65535 || gridRows > 32767 || (long long)gridCols * gridRows > kMaxCells ||
+        (long long)gridCols * gridRows * std::min(std::max(nLevels, 1), 32) > kMaxTableEntries)
+        return ORBFE_ERR_UNSUPPORTED;
     ProjArgs A{};
     A.B = B; A.M = M; A.kpStride = kpStride;
     A.g = GridDesc{gridCols, gridRows, minX, minY, invW, invH};
