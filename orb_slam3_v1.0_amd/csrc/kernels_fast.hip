@@ -153,7 +153,6 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH][kImgW];
     __shared__ __attribute__((aligned(16))) uint32_t sTmp[kTmpH / 2][kFastTW];  // row pairs of horizontal sums
     __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH][kScPitch];
-    __shared__ uint32_t sCnt4[4];  // per-wave totals of the stage-A scan
     __shared__ uint32_t sCand[kMaxTileCand];
     __shared__ uint32_t sCnt[4];  // tile: survivors, high survivors, pre-NMS low, pre-NMS high
     __shared__ uint32_t sBase;
@@ -337,53 +336,48 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     // tested region 6 <= x <= w-6, 6 <= y <= h-6 (Fast_gpu.cu:275,365-368: strict compares
     // against border 5 and dim-5); scores are needed for the tile + 1-px halo (NMS)
     // stage A: compass test on every position, survivors -> queue A; scores default to 0.
-    // Column strips: lane = score column, the 4 waves split the 34 score rows (9,9,8,8); LDS reads
-    // use immediate offsets from one running pointer, pass flags accumulate in a per-lane bit mask
-    // and ONE block scan compacts them.  Score columns 64,65 (right halo) take one extra
-    // evaluation on threads 0..67 (bit 9 of the mask).
+    // Column strips: lane = score column, the 4 waves split the 34 score rows (9,9,8,8); the 68 positions of
+    // score columns 64,65 (right halo) fill the ninth slot of waves 2 and 3, so every wave does nine
+    // evaluations.  The pass flags stay wave-wide lane masks (the compare result itself): one LDS atomic per
+    // wave reserves its queue slots and v_mbcnt ranks the lanes -- no per-lane bit masks, no block scan.
     for (int e = tid; e < kScH * (kScPitch / 4); e += 256) reinterpret_cast<uint32_t*>(&sScore[0][0])[e] = 0;
-    uint32_t passMask = 0;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, provably uniform -> scalar loop bounds
-    const int syBeg = wv * 9 - (wv > 2 ? wv - 2 : 0);  // 0, 9, 18, 26
-    const int syEnd = min(syBeg + (wv < 2 ? 9 : 8), kScH);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, provably uniform
     {
+        const int syBeg = wv * 9 - (wv > 2 ? wv - 2 : 0);  // 0, 9, 18, 26
         const int px = x0 - 1 + lane;
         const bool xok = px > kEdge && px < w - kEdge;
-        // rows whose py is outside (kEdge, h-kEdge) are skipped wave-uniformly
-        const int lo = max(syBeg, kEdge + 2 - y0);          // py = y0-1+sy > kEdge
-        const int hi = min(syEnd, h - kEdge + 1 - y0);      // py < h-kEdge
-        const uint8_t* p = &sImg[lo + 3][lane + 3];
-        for (int sy = lo; sy < hi; sy++, p += kImgW)
-            passMask |= (uint32_t)(xok && compass_pass_ptr(p, minTh)) << (sy - syBeg);
-    }
-    if (tid < 2 * kScH) {
-        const int sy = tid >> 1, sx = kFastTW + (tid & 1);
-        const int px = x0 - 1 + sx, py = y0 - 1 + sy;
-        if (px > kEdge && px < w - kEdge && py > kEdge && py < h - kEdge)
-            passMask |= (uint32_t)compass_pass_ptr(&sImg[sy + 3][sx + 3], minTh) << 9;
-    }
-    {
-        // block-wide exclusive scan of popc(passMask) -> queue offsets
-        const int cntA = __popc(passMask);
-        int incl = cntA;
+        bool fl[9];
+        int ent[9];
 #pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const int o = __shfl_up(incl, dlt);
-            if (lane >= dlt) incl += o;
+        for (int k = 0; k < 9; k++) {
+            int sy = syBeg + k, sx = lane;
+            bool ok = xok;
+            if (k == 8 && wv >= 2) {  // wave-uniform: halo positions 0..63 (wave 2) and 64..67 (wave 3)
+                const int hp = lane + 64 * (wv - 2);
+                sy = min(hp >> 1, kScH - 1);
+                sx = kFastTW + (hp & 1);
+                const int qx = x0 - 1 + sx;
+                ok = hp < 2 * kScH && qx > kEdge && qx < w - kEdge;
+            }
+            const int py = y0 - 1 + sy;
+            ok = ok && py > kEdge && py < h - kEdge;
+            fl[k] = compass_pass_ptr(&sImg[sy + 3][sx + 3], minTh) && ok;
+            ent[k] = (sy << 7) | sx;
         }
-        if (lane == 63) sCnt4[wv] = (uint32_t)incl;
-        __syncthreads();
-        int base = incl - cntA;
+        uint32_t tot = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (q < wv) base += (int)sCnt4[q];
-        if (tid == 255) sQ[0] = (uint32_t)(base + cntA);
-        uint32_t m = passMask;
-        while (m) {
-            const int b = __ffs(m) - 1;
-            m &= m - 1;
-            const int e = b < 9 ? ((syBeg + b) << 7) | lane : ((tid >> 1) << 7) | (kFastTW + (tid & 1));
-            sQA[base++] = (uint16_t)e;
+        for (int k = 0; k < 9; k++) tot += (uint32_t)__popcll(__ballot(fl[k]));
+        uint32_t base = 0;
+        if (tot) {  // wave-uniform
+            if (lane == 0) base = atomicAdd(&sQ[0], tot);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const unsigned long long m = __ballot(fl[k]);
+                if (fl[k])
+                    sQA[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base))] = (uint16_t)ent[k];
+                base += (uint32_t)__popcll(m);
+            }
         }
     }
     __syncthreads();
