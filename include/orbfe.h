@@ -222,6 +222,48 @@ int orbfe_match_initialization(orbfe_handle *h, const orbfe_frame_view *f1, cons
                                int *matches12_out, int *n_matches);
 
 /* -------------------------------------------------------------------------------------------
+ * Map-point projection: Frame::isInFrustum for a batch
+ * ---------------------------------------------------------------------------------------- */
+#define ORBFE_CAMERA_PINHOLE 0
+
+/* what Frame::isInFrustum reads from the frame (src/Frame.cc:272-331) */
+typedef struct orbfe_frustum {
+    float rcw[9];             /* GetRcw(), row-major */
+    float tcw[3];             /* GetTcw() */
+    float twc[3];             /* GetTwc() (camera centre) */
+    float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+    float fx, fy, cx, cy;     /* Pinhole mvParameters[0..3] (src/CameraModels/Pinhole.cpp:41-47) */
+    float mbf;                /* stereo baseline * fx (mTrackProjXR) */
+    float log_scale_factor;   /* mfLogScaleFactor (src/Frame.cc:75) */
+    int n_levels;             /* mnScaleLevels */
+    int camera_model;         /* ORBFE_CAMERA_PINHOLE */
+} orbfe_frustum;
+
+/* what it reads from a MapPoint, plus the two skip conditions of Tracking::SearchLocalPoints
+ * (src/Tracking.cc:1066-1069) */
+typedef struct orbfe_world_point {
+    float x, y, z;            /* GetWorldPos() */
+    float min_distance;       /* mfMinDistance (GetMinDistanceInvariance() == 0.9f * this) */
+    float max_distance;       /* mfMaxDistance (GetMaxDistanceInvariance() == 1.1f * this) */
+    int bad;                  /* isBad() */
+    int observations;         /* Observations() (passed through to the matcher record) */
+    int skip;                 /* mnLastFrameSeen == current frame id */
+} orbfe_world_point;
+
+/* replaces the isInFrustum loop of Tracking::SearchLocalPoints (src/Tracking.cc:1059-1077): out[i] holds
+ * the fields the reference writes into the MapPoint (mTrackProjX/Y, mTrackViewCos, mTrackDepth,
+ * mnTrackScaleLevel, mbTrackInView), i.e. the input records of orbfe_match_projection; proj_xr
+ * (mTrackProjXR) may be NULL.  HOST pointers.  Points that fail keep in_view == 0; proj_x / proj_y are -1 unless
+ * the projection landed inside the image bounds (as the reference leaves them). */
+int orbfe_project_map_points(orbfe_handle *h, const orbfe_frustum *frustum, int n,
+                             const orbfe_world_point *points, orbfe_map_point *out, float *proj_xr);
+/* Same with DEVICE pointers, asynchronous on `stream` (NULL == the handle's stream): the output feeds
+ * orbfe_match_projection_batch_device directly. */
+int orbfe_project_map_points_device(orbfe_handle *h, const orbfe_frustum *frustum, int n,
+                                    const orbfe_world_point *d_points, orbfe_map_point *d_out,
+                                    float *d_proj_xr, void *stream);
+
+/* -------------------------------------------------------------------------------------------
  * Vocabulary tree: the per-feature part of Frame::ComputeBoW
  * ---------------------------------------------------------------------------------------- */
 typedef struct orbfe_vocab orbfe_vocab;

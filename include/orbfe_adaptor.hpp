@@ -257,6 +257,47 @@ public:
     }
 };
 
+// The isInFrustum loop of Tracking::SearchLocalPoints (src/Tracking.cc:1059-1077) for all local map points in one
+// launch.  `frustum` carries what Frame::isInFrustum reads from the frame (GetRcw / GetTcw / GetTwc, image bounds,
+// pinhole intrinsics, mbf, mfLogScaleFactor, mnScaleLevels); `MapPoint` needs GetWorldPos() (indexable [0..2]),
+// mfMinDistance / mfMaxDistance (the RAW values: the public getters return them scaled by 0.9 / 1.1), isBad(),
+// Observations(), mnLastFrameSeen, and the mTrack* fields the reference writes.  Returns nToMatch.
+struct LocalPointProjector {
+    template <class MapPointPtr>
+    static int ProjectLocalMapPoints(orbfe_handle* h, const orbfe_frustum& frustum, long unsigned int currentFrameId,
+                                     const std::vector<MapPointPtr>& vpLocalMapPoints)
+    {
+        const int n = (int)vpLocalMapPoints.size();
+        std::vector<orbfe_world_point> pts(n > 0 ? n : 1);
+        for (int i = 0; i < n; i++) {
+            const auto& pMP = vpLocalMapPoints[i];
+            const auto P = pMP->GetWorldPos();
+            pts[i] = orbfe_world_point{P[0], P[1], P[2], pMP->mfMinDistance, pMP->mfMaxDistance, pMP->isBad() ? 1 : 0,
+                                       pMP->Observations(), pMP->mnLastFrameSeen == currentFrameId ? 1 : 0};
+        }
+        std::vector<orbfe_map_point> out(n > 0 ? n : 1);
+        std::vector<float> xr(n > 0 ? n : 1);
+        orbfe_detail::check(orbfe_project_map_points(h, &frustum, n, pts.data(), out.data(), xr.data()), h,
+                            "orbfe_project_map_points");
+        int nToMatch = 0;
+        for (int i = 0; i < n; i++) {
+            if (pts[i].skip || pts[i].bad) continue;  // :1066-1069: untouched
+            const auto& pMP = vpLocalMapPoints[i];
+            pMP->mbTrackInView = out[i].in_view != 0;  // src/Frame.cc:274-276
+            pMP->mTrackProjX = out[i].proj_x;
+            pMP->mTrackProjY = out[i].proj_y;
+            if (out[i].in_view) {  // :319-328
+                pMP->mTrackProjXR = xr[i];
+                pMP->mTrackDepth = out[i].track_depth;
+                pMP->mnTrackScaleLevel = out[i].level;
+                pMP->mTrackViewCos = out[i].view_cos;
+                nToMatch++;  // the caller still does pMP->IncreaseVisible() (:1073)
+            }
+        }
+        return nToMatch;
+    }
+};
+
 // ORB_SLAM3::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:29-30), the
 // part Frame::ComputeBoW / KeyFrame::ComputeBoW use (src/Frame.cc:483-495): load the text vocabulary, transform a
 // frame's descriptors into BowVector + FeatureVector.  The tree descent of every feature runs on the GPU

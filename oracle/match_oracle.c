@@ -389,3 +389,85 @@ void orc_vocab_transform(int nNodes, const int *childOff, const int *childIdx, c
         if (weightOut) weightOut[f] = weight[final_id];
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Frame::isInFrustum (src/Frame.cc:272-331) for a batch of map points, with
+ * MapPoint::PredictScale (src/MapPoint.cc:572-587) and Pinhole::project (src/CameraModels/Pinhole.cpp:41-47).
+ * SPEC DECISION S8: every float expression is evaluated left to right in binary32 with no
+ * contraction (the reference's Eigen expressions compile to whatever -march=native allows), norms are
+ * sqrtf((x*x + y*y) + z*z), and log() is orc_spec_logf below (the reference calls the platform libm).
+ * ------------------------------------------------------------------------------------------ */
+float orc_spec_logf(float x)
+{
+    /* x = m * 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716:
+     * 2s (1 + z/3 + z^2/5 + z^3/7 + z^4/9), z = s^2 (the next term is below 2^-28 relative) */
+    if (!(x > 0.0f)) return -INFINITY;
+    if (x > 3.0e38f) return INFINITY;
+    int e;
+    float m = frexpf(x, &e); /* exact */
+    if (m < 0x1.6a09e6p-1f) {
+        m = m * 2.0f;
+        e -= 1;
+    }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    float p = 0x1.c71c72p-4f;
+    p = p * z + 0x1.24924ap-3f;
+    p = p * z + 0x1.99999ap-3f;
+    p = p * z + 0x1.555556p-2f;
+    p = p * z;
+    const float t = s + s;
+    const float r = t + t * p;
+    const float ef = (float)e;
+    return ef * 0x1.62ep-1f + (r + ef * 0x1.0bfbe8p-15f);
+}
+
+void orc_is_in_frustum(const orc_frustum *F, int n, const orc_world_point *pts, orc_map_point *out, float *projXR)
+{
+    for (int i = 0; i < n; i++) {
+        const orc_world_point *p = &pts[i];
+        orc_map_point *o = &out[i];
+        o->projX = -1.0f; /* :275-276 */
+        o->projY = -1.0f;
+        o->viewCos = 0.0f;
+        o->trackDepth = 0.0f;
+        o->level = 0;
+        o->inView = 0;
+        o->bad = p->bad;
+        o->observations = p->observations;
+        if (projXR) projXR[i] = 0.0f;
+        if (p->skip || p->bad) continue; /* src/Tracking.cc:1066-1069 */
+        const float X = p->x, Y = p->y, Z = p->z;
+        const float pcx = ((F->rcw[0] * X + F->rcw[1] * Y) + F->rcw[2] * Z) + F->tcw[0]; /* :282 */
+        const float pcy = ((F->rcw[3] * X + F->rcw[4] * Y) + F->rcw[5] * Z) + F->tcw[1];
+        const float pcz = ((F->rcw[6] * X + F->rcw[7] * Y) + F->rcw[8] * Z) + F->tcw[2];
+        const float pcDist = sqrtf((pcx * pcx + pcy * pcy) + pcz * pcz);
+        const float invz = 1.0f / pcz;
+        if (pcz < 0.0f) continue; /* :288 */
+        const float u = F->fx * pcx / pcz + F->cx; /* Pinhole.cpp:43-44 */
+        const float v = F->fy * pcy / pcz + F->cy;
+        if (u < F->minX || u > F->maxX) continue; /* NaN (pcz == 0 with pcx == 0) passes, as in the reference */
+        if (v < F->minY || v > F->maxY) continue;
+        o->projX = u; /* :299-300: set before the distance test */
+        o->projY = v;
+        const float maxD = 1.1f * p->maxDistance, minD = 0.9f * p->minDistance; /* MapPoint.cc:543-553 */
+        const float ox = X - F->twc[0], oy = Y - F->twc[1], oz = Z - F->twc[2];
+        const float dist = sqrtf((ox * ox + oy * oy) + oz * oz);
+        if (dist < minD || dist > maxD) continue;
+        /* PredictScale */
+        const float ratio = p->maxDistance / dist;
+        const float q = orc_spec_logf(ratio) / F->logScaleFactor;
+        int nScale;
+        if (!(q > 0.0f)) nScale = 0; /* covers q <= 0 and NaN (the reference's int conversion is undefined there) */
+        else if (q >= (float)F->nLevels) nScale = F->nLevels - 1;
+        else {
+            nScale = (int)ceilf(q);
+            if (nScale >= F->nLevels) nScale = F->nLevels - 1;
+        }
+        o->inView = 1;
+        o->level = nScale;
+        o->viewCos = 1.0f; /* :316: the normal test is disabled in this fork */
+        o->trackDepth = pcDist;
+        if (projXR) projXR[i] = u - F->mbf * invz;
+    }
+}

@@ -131,6 +131,21 @@ void orc_vocab_transform(int nNodes, const int *childOff, const int *childIdx, c
                          const int *wordId, const double *weight, int L, const uint8_t *desc, int n,
                          int levelsup, int *wordOut, int *nodeOut, double *weightOut);
 
+/* Frame::isInFrustum for a batch of map points (src/Frame.cc:272-331), SPEC DECISION S8 */
+typedef struct {
+    float rcw[9], tcw[3], twc[3];
+    float minX, maxX, minY, maxY;
+    float fx, fy, cx, cy;
+    float mbf, logScaleFactor;
+    int nLevels, cameraModel;
+} orc_frustum;
+typedef struct {
+    float x, y, z, minDistance, maxDistance;
+    int bad, observations, skip;
+} orc_world_point;
+float orc_spec_logf(float x);
+void orc_is_in_frustum(const orc_frustum *F, int n, const orc_world_point *pts, orc_map_point *out, float *projXR);
+
 /* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480): linear cell per kp or -1 */
 void orc_assign_grid(const orc_frame_view *F, int *cellOut);
 

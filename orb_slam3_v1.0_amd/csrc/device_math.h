@@ -100,4 +100,30 @@ __device__ __forceinline__ void cos_sin_deg(float deg, float& c, float& s)
     }
 }
 
+// SPEC DECISION S8: natural logarithm of MapPoint::PredictScale (src/MapPoint.cc:580), same operation
+// sequence as oracle/match_oracle.c orc_spec_logf: x = m * 2^e, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s)
+// with s = (m-1)/(m+1) as a degree-4 polynomial in s^2; contraction is off for this translation unit.
+__device__ __forceinline__ float spec_logf(float x)
+{
+    if (!(x > 0.0f)) return -INFINITY;
+    if (x > 3.0e38f) return INFINITY;
+    int e;
+    float m = frexpf(x, &e);
+    if (m < 0x1.6a09e6p-1f) {
+        m = m * 2.0f;
+        e -= 1;
+    }
+    const float s = __fdiv_rn(m - 1.0f, m + 1.0f);
+    const float z = s * s;
+    float p = 0x1.c71c72p-4f;
+    p = p * z + 0x1.24924ap-3f;
+    p = p * z + 0x1.99999ap-3f;
+    p = p * z + 0x1.555556p-2f;
+    p = p * z;
+    const float t = s + s;
+    const float r = t + t * p;
+    const float ef = (float)e;
+    return ef * 0x1.62ep-1f + (r + ef * 0x1.0bfbe8p-15f);
+}
+
 }  // namespace orbfe

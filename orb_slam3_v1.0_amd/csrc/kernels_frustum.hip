@@ -1,0 +1,100 @@
+// kernels_frustum.hip -- Frame::isInFrustum for all local map points of a frame in one launch
+// (SURVEY.md section 8f, row f3).
+//
+// Replaces the per-point loop of Tracking::SearchLocalPoints (src/Tracking.cc:1059-1077) ->
+// Frame::isInFrustum (src/Frame.cc:272-331) -> Pinhole::project (src/CameraModels/Pinhole.cpp:41-47) and
+// MapPoint::PredictScale (src/MapPoint.cc:572-587).  The output records are exactly what
+// SearchByProjection reads (orbfe_map_point), so projection and matching chain on the device with no
+// host round trip in between.  One thread per map point; 32 B read + 32 B written per point.
+// SPEC DECISION S8: binary32, left-to-right, no contraction, sqrtf((x*x + y*y) + z*z), spec_logf.
+// (sqrtf and "/" are correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt; the
+// __fsqrt_rn intrinsic is NOT -- it maps to the native approximate square root.)
+#include <string>
+
+#include "device_math.h"
+#include "match.h"
+
+#pragma clang fp contract(off)
+
+namespace orbfe {
+
+namespace {
+
+__global__ __launch_bounds__(256) void frustum_kernel(orbfe_frustum F, int n, const orbfe_world_point* __restrict__ pts,
+                                                      orbfe_map_point* __restrict__ out, float* __restrict__ projXR)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const orbfe_world_point p = pts[i];
+    orbfe_map_point o;
+    o.proj_x = -1.0f;  // :275-276
+    o.proj_y = -1.0f;
+    o.view_cos = 0.0f;
+    o.track_depth = 0.0f;
+    o.level = 0;
+    o.in_view = 0;
+    o.bad = p.bad;
+    o.observations = p.observations;
+    float xr = 0.0f;
+    do {
+        if (p.skip || p.bad) break;  // src/Tracking.cc:1066-1069
+        const float X = p.x, Y = p.y, Z = p.z;
+        const float pcx = ((F.rcw[0] * X + F.rcw[1] * Y) + F.rcw[2] * Z) + F.tcw[0];  // :282
+        const float pcy = ((F.rcw[3] * X + F.rcw[4] * Y) + F.rcw[5] * Z) + F.tcw[1];
+        const float pcz = ((F.rcw[6] * X + F.rcw[7] * Y) + F.rcw[8] * Z) + F.tcw[2];
+        const float pcDist = sqrtf((pcx * pcx + pcy * pcy) + pcz * pcz);
+        const float invz = __fdiv_rn(1.0f, pcz);
+        if (pcz < 0.0f) break;  // :288
+        const float u = __fdiv_rn(F.fx * pcx, pcz) + F.cx;  // Pinhole.cpp:43-44
+        const float v = __fdiv_rn(F.fy * pcy, pcz) + F.cy;
+        if (u < F.min_x || u > F.max_x) break;
+        if (v < F.min_y || v > F.max_y) break;
+        o.proj_x = u;  // :299-300: set before the distance test
+        o.proj_y = v;
+        const float maxD = 1.1f * p.max_distance, minD = 0.9f * p.min_distance;  // MapPoint.cc:543-553
+        const float ox = X - F.twc[0], oy = Y - F.twc[1], oz = Z - F.twc[2];
+        const float dist = sqrtf((ox * ox + oy * oy) + oz * oz);
+        if (dist < minD || dist > maxD) break;
+        const float ratio = __fdiv_rn(p.max_distance, dist);
+        const float q = __fdiv_rn(spec_logf(ratio), F.log_scale_factor);
+        int nScale;
+        if (!(q > 0.0f)) nScale = 0;
+        else if (q >= (float)F.n_levels) nScale = F.n_levels - 1;
+        else {
+            nScale = (int)ceilf(q);
+            if (nScale >= F.n_levels) nScale = F.n_levels - 1;
+        }
+        o.in_view = 1;
+        o.level = nScale;
+        o.view_cos = 1.0f;  // :316: the normal test is disabled in this fork
+        o.track_depth = pcDist;
+        xr = u - F.mbf * invz;
+    } while (false);
+    out[i] = o;
+    if (projXR) projXR[i] = xr;
+}
+
+}  // namespace
+
+int frustum_validate(const orbfe_frustum* F)
+{
+    if (!F) return ORBFE_ERR_INVALID_ARG;
+    if (F->camera_model != ORBFE_CAMERA_PINHOLE) return ORBFE_ERR_UNSUPPORTED;  // KannalaBrandt8: not built yet
+    if (F->n_levels < 1 || !(F->log_scale_factor > 0.0f)) return ORBFE_ERR_INVALID_ARG;
+    return ORBFE_OK;
+}
+
+int frustum_launch(hipStream_t s, const orbfe_frustum* F, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,
+                   float* dProjXR, std::string& err)
+{
+    if (n == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(frustum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *F, n, dPts, dOut, dProjXR);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        err = std::string("frustum_kernel: ") + hipGetErrorString(e);
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+}  // namespace orbfe

@@ -37,4 +37,9 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
                   int nF, const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation,
                   int* matchOut, int* nMatches, std::string& err);
 
+// kernels_frustum.hip
+int frustum_validate(const orbfe_frustum* F);
+int frustum_launch(hipStream_t s, const orbfe_frustum* F, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,
+                   float* dProjXR, std::string& err);
+
 }  // namespace orbfe

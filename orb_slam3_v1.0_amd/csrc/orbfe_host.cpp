@@ -16,6 +16,7 @@
 
 #include "launch.h"
 #include "match.h"
+#include "match_common.h"
 #include "vocab.h"
 
 using namespace orbfe;
@@ -610,6 +611,54 @@ int orbfe_match_initialization(orbfe_handle* h, const orbfe_frame_view* F1, cons
                                       n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
+}
+
+int orbfe_project_map_points_device(orbfe_handle* h, const orbfe_frustum* frustum, int n, const orbfe_world_point* d_points,
+                                    orbfe_map_point* d_out, float* d_proj_xr, void* stream)
+{
+    if (!h || n < 0 || (n > 0 && (!d_points || !d_out))) return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = frustum_launch(stream ? static_cast<hipStream_t>(stream) : h->stream, frustum, n, d_points, d_out, d_proj_xr, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+int orbfe_project_map_points(orbfe_handle* h, const orbfe_frustum* frustum, int n, const orbfe_world_point* points,
+                             orbfe_map_point* out, float* proj_xr)
+{
+    if (!h || n < 0 || (n > 0 && (!points || !out))) return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    if (n == 0) return ORBFE_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    // staging through the matcher's grow-only arenas: [points | out | xr] on both sides
+    const size_t bIn = (size_t)n * sizeof(orbfe_world_point), bOut = (size_t)n * sizeof(orbfe_map_point), bXr = (size_t)n * sizeof(float);
+    std::string err;
+    int rc = ensure(h->match, bIn + bOut + bXr + 256, bIn + bOut + bXr + 256, err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    uint8_t* dp = static_cast<uint8_t*>(h->match.d);
+    uint8_t* hp = static_cast<uint8_t*>(h->match.hpin);
+    memcpy(hp, points, bIn);
+    HIPCHK(h, hipMemcpyAsync(dp, hp, bIn, hipMemcpyHostToDevice, h->stream));
+    rc = frustum_launch(h->stream, frustum, n, reinterpret_cast<const orbfe_world_point*>(dp),
+                        reinterpret_cast<orbfe_map_point*>(dp + bIn), reinterpret_cast<float*>(dp + bIn + bOut), err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(hp + bIn, dp + bIn, bOut + bXr, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(out, hp + bIn, bOut);
+    if (proj_xr) memcpy(proj_xr, hp + bIn + bOut, bXr);
+    return ORBFE_OK;
 }
 
 struct orbfe_vocab {

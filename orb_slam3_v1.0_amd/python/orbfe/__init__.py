@@ -19,6 +19,8 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<i4"), ("size", "
                      ("octave", "<i4"), ("angle", "<f4")])
 MP_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("view_cos", "<f4"), ("track_depth", "<f4"),
                      ("level", "<i4"), ("in_view", "<i4"), ("bad", "<i4"), ("observations", "<i4")])
+WP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("min_distance", "<f4"), ("max_distance", "<f4"),
+                     ("bad", "<i4"), ("observations", "<i4"), ("skip", "<i4")])
 NUM_STAGES = 5
 
 STATUS = {0: "ORBFE_OK", 1: "ORBFE_ERR_INVALID_ARG", 2: "ORBFE_ERR_UNSUPPORTED", 3: "ORBFE_ERR_NO_DEVICE",
@@ -38,6 +40,14 @@ class Params(C.Structure):
                 ("max_batch", C.c_int)]
 
 
+class Frustum(C.Structure):
+    """orbfe_frustum: what Frame::isInFrustum reads from the frame (src/Frame.cc:272-331)."""
+    _fields_ = [("rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("twc", C.c_float * 3), ("min_x", C.c_float),
+                ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float), ("log_scale_factor", C.c_float),
+                ("n_levels", C.c_int), ("camera_model", C.c_int)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int), ("kp", C.c_void_p), ("desc", C.c_void_p), ("grid_cols", C.c_int),
                 ("grid_rows", C.c_int), ("min_x", C.c_float), ("min_y", C.c_float),
@@ -51,7 +61,8 @@ SYMBOLS = [
     "orbfe_get_level_info", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
-    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
+    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
@@ -109,6 +120,8 @@ def lib():
                                                       cf, ci, cf, cf, vp, vp, vp]
     L.orbfe_match_bow.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp, vp]
     L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
+    L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
+    L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_vocab_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocab_destroy.argtypes = [vp]
     L.orbfe_vocab_destroy.restype = None
@@ -296,6 +309,21 @@ class ORBmatcher:
             self.e.h, batch, d_kp, d_desc, d_n, kp_stride, gridCols, gridRows, minX, minY, invw, invh, M, d_mps,
             d_mp_desc, d_init_obs, th, int(bFarPoints), thFarPoints, nnRatio, d_match_out, d_n_matches, stream),
             "orbfe_match_projection_batch_device")
+
+    def isInFrustum_batch(self, frustum, points):
+        """The isInFrustum loop of Tracking::SearchLocalPoints (src/Tracking.cc:1059-1077) for all points at once:
+        returns (map point records for SearchByProjection, mTrackProjXR)."""
+        points = np.ascontiguousarray(points, WP_DTYPE)
+        n = len(points)
+        out = np.zeros(max(n, 1), MP_DTYPE)
+        xr = np.zeros(max(n, 1), np.float32)
+        self.e._chk(self.L.orbfe_project_map_points(self.e.h, C.byref(frustum), n, _p(points), _p(out), _p(xr)),
+                    "orbfe_project_map_points")
+        return out[:n], xr[:n]
+
+    def isInFrustum_batch_device(self, frustum, n, d_points, d_out, d_proj_xr=None, stream=None):
+        self.e._chk(self.L.orbfe_project_map_points_device(self.e.h, C.byref(frustum), n, d_points, d_out, d_proj_xr,
+                                                           stream), "orbfe_project_map_points_device")
 
     def SearchForInitialization(self, fv1, fv2, windowSize, nnRatio, checkOrientation=True):
         """include/ORBmatcher.h:58 -> (nmatches, vnMatches12)."""

@@ -13,6 +13,10 @@ struct MapPoint {
     bool mbTrackInView = true;
     float mTrackDepth = 1.f, mTrackViewCos = 1.f, mTrackProjX = 0.f, mTrackProjY = 0.f;
     int mnTrackScaleLevel = 0, obs = 1;
+    float mTrackProjXR = 0.f, mfMinDistance = 0.5f, mfMaxDistance = 30.f;
+    long unsigned int mnLastFrameSeen = 0;
+    float wp[3] = {0.f, 0.f, 1.f};
+    const float* GetWorldPos() const { return wp; }
     bool bad = false;
     uint8_t desc[32];
     bool isBad() const { return bad; }
@@ -99,6 +103,27 @@ int main(int argc, char** argv)
             std::fprintf(fo, "\n");
         }
         fclose(fo);
+    }
+    {  // Tracking::SearchLocalPoints, src/Tracking.cc:1059-1077: project a deterministic cloud (identity pose)
+        std::vector<std::shared_ptr<MapPoint>> cloud;
+        for (int j = 0; j < 3000; j++) {
+            auto mp = std::make_shared<MapPoint>();
+            mp->wp[0] = (float)(j % 37 - 18) * 0.25f;
+            mp->wp[1] = (float)(j % 23 - 11) * 0.2f;
+            mp->wp[2] = 2.0f + (float)(j % 11);
+            mp->bad = j % 97 == 0;
+            mp->mnLastFrameSeen = j % 53 == 0 ? 7 : 0;
+            cloud.push_back(mp);
+        }
+        orbfe_frustum fr{};
+        fr.rcw[0] = fr.rcw[4] = fr.rcw[8] = 1.0f;
+        fr.min_x = 0.f; fr.max_x = (float)W; fr.min_y = 0.f; fr.max_y = (float)H;
+        fr.fx = fr.fy = 400.f; fr.cx = 0.5f * (float)W; fr.cy = 0.5f * (float)H;
+        fr.mbf = 40.f; fr.log_scale_factor = 0.18232156f; fr.n_levels = 8; fr.camera_model = ORBFE_CAMERA_PINHOLE;
+        const int nToMatch = LocalPointProjector::ProjectLocalMapPoints(ex.handle(), fr, 7, cloud);
+        long lvlSum = 0;
+        for (auto& mp : cloud) if (mp->mbTrackInView) lvlSum += mp->mnTrackScaleLevel;
+        std::printf("frustum nToMatch=%d levelSum=%ld\n", nToMatch, lvlSum);
     }
     std::printf("adaptor ok: %d keypoints, %d matches, levels=%d scale=%g\n", n, nm, ex.GetLevels(), ex.GetScaleFactor());
     return 0;

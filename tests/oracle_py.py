@@ -16,6 +16,17 @@ MP_DTYPE = np.dtype([("projX", "<f4"), ("projY", "<f4"), ("viewCos", "<f4"), ("t
                      ("level", "<i4"), ("inView", "<i4"), ("bad", "<i4"), ("observations", "<i4")])
 
 
+WP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("minDistance", "<f4"), ("maxDistance", "<f4"),
+                     ("bad", "<i4"), ("observations", "<i4"), ("skip", "<i4")])
+
+
+class Frustum(C.Structure):
+    _fields_ = [("rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("twc", C.c_float * 3), ("minX", C.c_float),
+                ("maxX", C.c_float), ("minY", C.c_float), ("maxY", C.c_float), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float), ("logScaleFactor", C.c_float),
+                ("nLevels", C.c_int), ("cameraModel", C.c_int)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int), ("kp", C.c_void_p), ("desc", C.c_void_p), ("gridCols", C.c_int),
                 ("gridRows", C.c_int), ("minX", C.c_float), ("minY", C.c_float),
@@ -70,6 +81,10 @@ def lib():
         L.orc_search_for_initialization.argtypes = [vp, vp, ci, cf, ci, vp]
         L.orc_vocab_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, vp]
         L.orc_vocab_transform.restype = None
+        L.orc_spec_logf.argtypes = [cf]
+        L.orc_spec_logf.restype = cf
+        L.orc_is_in_frustum.argtypes = [C.POINTER(Frustum), ci, vp, vp, vp]
+        L.orc_is_in_frustum.restype = None
         _lib = L
     return _lib
 
@@ -260,3 +275,16 @@ def vocab_transform(childOff, childIdx, nodeDesc, wordId, weight, L, desc, level
     lib().orc_vocab_transform(len(wordId), _p(childOff), _p(childIdx), _p(nodeDesc), _p(wordId), _p(weight), int(L),
                               _p(desc), n, int(levelsup), _p(word), _p(node), _p(w))
     return word[:n], node[:n], w[:n]
+
+
+def spec_logf(x):
+    return float(lib().orc_spec_logf(float(np.float32(x))))
+
+
+def is_in_frustum(frustum, points):
+    points = np.ascontiguousarray(points, WP_DTYPE)
+    n = len(points)
+    out = np.zeros(max(n, 1), MP_DTYPE)
+    xr = np.zeros(max(n, 1), np.float32)
+    lib().orc_is_in_frustum(C.byref(frustum), n, _p(points), _p(out), _p(xr))
+    return out[:n], xr[:n]

@@ -46,8 +46,22 @@ def test_adaptor_matches_oracle(built, tmp_path):
     from test_vocab import ref_bow
     tree = vs.make_tree(10, 5, seed=9, early_leaf_p=0.03)
     vs.write_text(tree, str(tmp_path / "voc.txt"))
-    subprocess.check_call([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "m.bin"), str(M), str(tmp_path / "o.bin"),
-                           str(tmp_path / "voc.txt"), str(tmp_path / "bow.txt")])
+    stdout = subprocess.check_output([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "m.bin"), str(M),
+                                      str(tmp_path / "o.bin"), str(tmp_path / "voc.txt"), str(tmp_path / "bow.txt")]).decode()
+    # LocalPointProjector::ProjectLocalMapPoints on the driver's deterministic cloud == the oracle
+    Fo = O.Frustum()
+    Fo.rcw[0] = Fo.rcw[4] = Fo.rcw[8] = 1.0
+    Fo.minX, Fo.maxX, Fo.minY, Fo.maxY = 0.0, float(W), 0.0, float(H)
+    Fo.fx = Fo.fy = 400.0
+    Fo.cx, Fo.cy, Fo.mbf, Fo.logScaleFactor, Fo.nLevels = 0.5 * W, 0.5 * H, 40.0, 0.18232156, 8
+    j = np.arange(3000)
+    cloud = np.zeros(3000, O.WP_DTYPE)
+    cloud["x"], cloud["y"], cloud["z"] = (j % 37 - 18) * np.float32(0.25), (j % 23 - 11) * np.float32(0.2), 2.0 + j % 11
+    cloud["minDistance"], cloud["maxDistance"] = 0.5, 30.0
+    cloud["bad"], cloud["skip"], cloud["observations"] = j % 97 == 0, j % 53 == 0, 1
+    fo, _ = O.is_in_frustum(Fo, cloud)
+    assert "frustum nToMatch=%d levelSum=%d" % (fo["inView"].sum(), fo["level"][fo["inView"] == 1].sum()) in stdout
+    assert fo["inView"].sum() > 500
     raw = (tmp_path / "o.bin").read_bytes()
     n, nm = np.frombuffer(raw[:8], np.int32)
     kp = np.frombuffer(raw[8:8 + 24 * n], orbfe.KP_DTYPE)
