@@ -263,6 +263,18 @@ int orbfe_project_map_points_device(orbfe_handle *h, const orbfe_frustum *frustu
                                     const orbfe_world_point *d_points, orbfe_map_point *d_out,
                                     float *d_proj_xr, void *stream);
 
+/* replaces the search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false)
+ * (src/ORBmatcher.cc:678-836; callers src/LocalMapping.cc:822,852): per map point the projection into the
+ * key frame, KeyFrame::IsInImage, PredictScale, KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:790-833), the
+ * chi-square gate and the nearest descriptor.  points[i].skip carries "!pMP || pMP->IsInKeyFrame(pKF)".
+ * inv_level_sigma2 = pKF->mvInvLevelSigma2 (KF->n_levels floats); u_right = pKF->mvuRight or NULL (monocular).
+ * best_idx_out[i] / best_dist_out[i] = bestIdx / bestDist of :776-826 (-1 / 256 when nothing qualified); the
+ * caller applies bestDist <= TH_LOW and the map-point graph edits (:829-849) in list order.  HOST pointers. */
+int orbfe_fuse_search(orbfe_handle *h, const orbfe_frame_view *KF, const float *inv_level_sigma2,
+                      const float *u_right, const orbfe_frustum *frustum, float th, int M,
+                      const orbfe_world_point *points, const uint8_t *mp_desc, int *best_idx_out,
+                      int *best_dist_out);
+
 /* -------------------------------------------------------------------------------------------
  * Vocabulary tree: the per-feature part of Frame::ComputeBoW
  * ---------------------------------------------------------------------------------------- */

@@ -471,3 +471,77 @@ void orc_is_in_frustum(const orc_frustum *F, int n, const orc_world_point *pts, 
         if (projXR) projXR[i] = u - F->mbf * invz;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * SURVEY 8f row f2 (first half): the search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false)
+ * (src/ORBmatcher.cc:678-836): per map point the projection (:722-766, SPEC DECISION S8 arithmetic;
+ * the reference applies Tcw through Sophus' quaternion form, here Rcw * p + tcw as in isInFrustum),
+ * KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:790-833) and the chi-square gated nearest descriptor
+ * (:779-826).  Returns bestIdx / bestDist per map point; the caller applies bestDist <= TH_LOW and the
+ * map-point graph edits (:829-849), which stay on the host in list order.
+ * pts[i].skip carries "!pMP || pMP->IsInKeyFrame(pKF)", pts[i].bad carries isBad() (:706-721).
+ * uRight == NULL means a monocular key frame (mvuRight[i] < 0 for all i).
+ * ------------------------------------------------------------------------------------------ */
+void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, const float *uRight, const orc_frustum *F,
+                     float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
+                     int *bestDistOut)
+{
+    cell_t *g = build_grid(KF);
+    int *vIndices = (int *)malloc(sizeof(int) * (size_t)(KF->n > 0 ? KF->n : 1));
+    for (int i = 0; i < M; i++) {
+        const orc_world_point *p = &pts[i];
+        bestIdxOut[i] = -1;
+        bestDistOut[i] = 256;
+        if (p->skip || p->bad) continue;
+        const float X = p->x, Y = p->y, Z = p->z;
+        const float pcx = ((F->rcw[0] * X + F->rcw[1] * Y) + F->rcw[2] * Z) + F->tcw[0];
+        const float pcy = ((F->rcw[3] * X + F->rcw[4] * Y) + F->rcw[5] * Z) + F->tcw[1];
+        const float pcz = ((F->rcw[6] * X + F->rcw[7] * Y) + F->rcw[8] * Z) + F->tcw[2];
+        if (pcz < 0.0f) continue; /* :725 */
+        const float invz = 1 / pcz;
+        const float u = F->fx * pcx / pcz + F->cx;
+        const float v = F->fy * pcy / pcz + F->cy;
+        if (!(u >= F->minX && u < F->maxX && v >= F->minY && v < F->maxY)) continue; /* KeyFrame::IsInImage */
+        const float ur = u - F->mbf * invz;
+        const float maxD = 1.1f * p->maxDistance, minD = 0.9f * p->minDistance;
+        const float ox = X - F->twc[0], oy = Y - F->twc[1], oz = Z - F->twc[2];
+        const float dist3D = sqrtf((ox * ox + oy * oy) + oz * oz);
+        if (dist3D < minD || dist3D > maxD) continue; /* :748 */
+        const float ratio = p->maxDistance / dist3D; /* PredictScale */
+        const float q = orc_spec_logf(ratio) / F->logScaleFactor;
+        int lvl;
+        if (!(q > 0.0f)) lvl = 0;
+        else if (q >= (float)F->nLevels) lvl = F->nLevels - 1;
+        else {
+            lvl = (int)ceilf(q);
+            if (lvl >= F->nLevels) lvl = F->nLevels - 1;
+        }
+        const float radius = th * KF->scaleFactors[lvl]; /* :766 */
+        const int nc = features_in_area(KF, g, u, v, radius, -1, -1, vIndices);
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = vIndices[c];
+            const orc_keypoint *kp = &KF->kp[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue; /* :787 */
+            if (uRight && uRight[idx] >= 0) {
+                const float ex = u - kp->x, ey = v - kp->y, er = ur - uRight[idx];
+                const float e2 = (ex * ex + ey * ey) + er * er;
+                if (e2 * invLevelSigma2[kpLevel] > 7.8) continue; /* float product against a double constant */
+            } else {
+                const float ex = u - kp->x, ey = v - kp->y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_hamming(mpDesc + (size_t)i * 32, KF->desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        bestIdxOut[i] = bestIdx;
+        bestDistOut[i] = bestDist;
+    }
+    free(vIndices);
+    free_grid(KF, g);
+}

@@ -146,6 +146,11 @@ typedef struct {
 float orc_spec_logf(float x);
 void orc_is_in_frustum(const orc_frustum *F, int n, const orc_world_point *pts, orc_map_point *out, float *projXR);
 
+/* the search part of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:678-836) */
+void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, const float *uRight, const orc_frustum *F,
+                     float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
+                     int *bestDistOut);
+
 /* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480): linear cell per kp or -1 */
 void orc_assign_grid(const orc_frame_view *F, int *cellOut);
 

@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "device_math.h"
 #include "match_common.h"
 
 #pragma clang fp contract(off)
@@ -99,6 +100,9 @@ struct MpWindow {
     int minCX, maxCX, minCY, maxCY, minLevel, maxLevel;
 };
 
+// cell range of GetFeaturesInArea (src/Frame.cc:413-435 == src/KeyFrame.cc:798-812) for a square of half-size r
+__device__ __forceinline__ void window_cells(const GridDesc& g, MpWindow& w);
+
 __device__ __forceinline__ MpWindow mp_window(const ProjArgs& A, const orbfe_map_point& mp)
 {
     MpWindow w;
@@ -110,19 +114,25 @@ __device__ __forceinline__ MpWindow mp_window(const ProjArgs& A, const orbfe_map
     w.r = r;
     w.x = mp.proj_x;
     w.y = mp.proj_y;
-    float t;
-    t = w.x - A.g.minX; t = t - r; t = t * A.g.invW;
-    w.minCX = max(0, (int)floorf(t));
-    t = w.x - A.g.minX; t = t + r; t = t * A.g.invW;
-    w.maxCX = min(A.g.cols - 1, (int)ceilf(t));
-    t = w.y - A.g.minY; t = t - r; t = t * A.g.invH;
-    w.minCY = max(0, (int)floorf(t));
-    t = w.y - A.g.minY; t = t + r; t = t * A.g.invH;
-    w.maxCY = min(A.g.rows - 1, (int)ceilf(t));
-    if (w.minCX >= A.g.cols || w.maxCX < 0 || w.minCY >= A.g.rows || w.maxCY < 0) w.valid = false;
+    window_cells(A.g, w);
     w.minLevel = lvl - 1;
     w.maxLevel = lvl;
     return w;
+}
+
+__device__ __forceinline__ void window_cells(const GridDesc& g, MpWindow& w)
+{
+    const float r = w.r;
+    float t;
+    t = w.x - g.minX; t = t - r; t = t * g.invW;
+    w.minCX = max(0, (int)floorf(t));
+    t = w.x - g.minX; t = t + r; t = t * g.invW;
+    w.maxCX = min(g.cols - 1, (int)ceilf(t));
+    t = w.y - g.minY; t = t - r; t = t * g.invH;
+    w.minCY = max(0, (int)floorf(t));
+    t = w.y - g.minY; t = t + r; t = t * g.invH;
+    w.maxCY = min(g.rows - 1, (int)ceilf(t));
+    if (w.minCX >= g.cols || w.maxCX < 0 || w.minCY >= g.rows || w.maxCY < 0) w.valid = false;
 }
 
 // the part of GetFeaturesInArea's candidate test that the cell range does not already imply:
@@ -618,6 +628,95 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
     if (tid == 0) A.nMatches[f] = sCount;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The search part of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:678-836), SURVEY 8f row f2:
+// thread per map point -- projection (SPEC DECISION S8 arithmetic, as frustum_kernel), KeyFrame::IsInImage,
+// PredictScale, KeyFrame::GetFeaturesInArea through the per-level cell-range tables, the chi-square gate
+// (:794-817) and the nearest descriptor under (distance, visit position) == the reference's strict "<" scan.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frustum F, float th, int M,
+                                                          const orbfe_world_point* __restrict__ pts,
+                                                          const uint8_t* __restrict__ mpDesc,
+                                                          const float* __restrict__ invLevelSigma2,
+                                                          const float* __restrict__ uRight, int* __restrict__ bestIdxOut,
+                                                          int* __restrict__ bestDistOut)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const orbfe_world_point p = pts[i];
+    int bestIdx = -1, bestDist = 256;
+    do {
+        if (p.skip || p.bad) break;  // :706-721
+        const float X = p.x, Y = p.y, Z = p.z;
+        const float pcx = ((F.rcw[0] * X + F.rcw[1] * Y) + F.rcw[2] * Z) + F.tcw[0];
+        const float pcy = ((F.rcw[3] * X + F.rcw[4] * Y) + F.rcw[5] * Z) + F.tcw[1];
+        const float pcz = ((F.rcw[6] * X + F.rcw[7] * Y) + F.rcw[8] * Z) + F.tcw[2];
+        if (pcz < 0.0f) break;  // :725
+        const float invz = 1.0f / pcz;
+        const float u = F.fx * pcx / pcz + F.cx;
+        const float v = F.fy * pcy / pcz + F.cy;
+        if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) break;  // KeyFrame::IsInImage
+        const float ur = u - F.mbf * invz;
+        const float maxD = 1.1f * p.max_distance, minD = 0.9f * p.min_distance;
+        const float ox = X - F.twc[0], oy = Y - F.twc[1], oz = Z - F.twc[2];
+        const float dist3D = sqrtf((ox * ox + oy * oy) + oz * oz);
+        if (dist3D < minD || dist3D > maxD) break;  // :748
+        const float ratio = p.max_distance / dist3D;  // PredictScale
+        const float q = spec_logf(ratio) / F.log_scale_factor;
+        int lvl;
+        if (!(q > 0.0f)) lvl = 0;
+        else if (q >= (float)F.n_levels) lvl = F.n_levels - 1;
+        else {
+            lvl = (int)ceilf(q);
+            if (lvl >= F.n_levels) lvl = F.n_levels - 1;
+        }
+        MpWindow w;
+        w.valid = true;
+        w.x = u;
+        w.y = v;
+        w.r = th * A.scaleFactors[lvl];  // :766
+        window_cells(A.g, w);
+        if (!w.valid) break;
+        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(mpDesc + (size_t)i * 32);
+        const unsigned long long d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
+        const int rows = A.g.rows;
+        const int tabStride = A.g.cols * rows + 1;
+        uint32_t best = kKey32None;
+        for (int l = max(lvl - 1, 0); l <= min(lvl, A.tabLevels - 1); l++) {  // :787
+            const int* csl = A.colStart + (size_t)l * tabStride;
+            const float invS2 = invLevelSigma2[l];
+            for (int cx = w.minCX; cx <= w.maxCX; cx++) {
+                const int s = csl[cx * rows + w.minCY], e = csl[cx * rows + w.maxCY + 1];
+                for (int sl = s; sl < e; sl++) {
+                    const int4 rq = A.rec[sl];
+                    const float kx = __int_as_float(rq.z), ky = __int_as_float(rq.w);
+                    if (!(fabsf(kx - u) < w.r && fabsf(ky - v) < w.r)) continue;  // src/KeyFrame.cc:826
+                    const float ex = u - kx, ey = v - ky;
+                    float kur = -1.0f;
+                    if (uRight) kur = uRight[A.order[rq.x]];
+                    if (kur >= 0) {  // :792-805
+                        const float er = ur - kur;
+                        const float e2 = (ex * ex + ey * ey) + er * er;
+                        if ((double)(e2 * invS2) > 7.8) continue;
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * invS2) > 5.99) continue;
+                    }
+                    const unsigned long long* kd = A.descS + (size_t)sl * 4;
+                    const int dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
+                    best = min(best, make_key32(dist, rq.x));
+                }
+            }
+        }
+        if (best != kKey32None) {
+            bestIdx = A.order[best & kRankMask];
+            bestDist = (int)(best >> kRankBits);
+        }
+    } while (false);
+    bestIdxOut[i] = bestIdx;
+    bestDistOut[i] = bestDist;
+}
+
 // Distance cut-off.  The verdict of src/ORBmatcher.cc:108-117 only depends on candidates below a bound:
 // a best candidate needs dist <= TH_HIGH, and a second-best with nnRatio * d2 >= TH_HIGH can never reject a
 // best <= TH_HIGH (the float product is monotone in d2) -- it acts exactly like "no second candidate".
@@ -798,6 +897,74 @@ int match_projection_batch_device(MatchScratch& m, hipStream_t s, int B, const o
     int rc = proj_setup(m, A, Carver(), 64, err);
     if (rc != ORBFE_OK) return rc;
     return proj_launch(s, A, err);
+}
+
+int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, const float* invLevelSigma2,
+                    const float* uRight, const orbfe_frustum* F, float th, int M, const orbfe_world_point* pts,
+                    const uint8_t* mpDesc, int* bestIdxOut, int* bestDistOut, std::string& err)
+{
+    for (int i = 0; i < M; i++) {
+        bestIdxOut[i] = -1;
+        bestDistOut[i] = 256;
+    }
+    const int n = KF->n;
+    if (n == 0 || M == 0) return ORBFE_OK;
+    if (n >= (1 << 20) || KF->grid_cols > 65535 || KF->grid_rows > 32767 || KF->n_levels < 1 ||
+        (long long)KF->grid_cols * KF->grid_rows > kMaxCells ||
+        (long long)KF->grid_cols * KF->grid_rows * std::min(KF->n_levels, 32) > kMaxTableEntries)
+        return ORBFE_ERR_UNSUPPORTED;
+    if (F->n_levels > KF->n_levels) return ORBFE_ERR_INVALID_ARG;  // predicted levels index the key frame's scale tables
+    Carver in;
+    const size_t oKp = in.take((size_t)n * sizeof(orbfe_keypoint));
+    const size_t oDesc = in.take((size_t)n * 32);
+    const size_t oPts = in.take((size_t)M * sizeof(orbfe_world_point));
+    const size_t oMpDesc = in.take((size_t)M * 32);
+    const size_t oSf = in.take((size_t)KF->n_levels * sizeof(float));
+    const size_t oIs2 = in.take((size_t)KF->n_levels * sizeof(float));
+    const size_t oUr = in.take((size_t)n * sizeof(float));
+    const size_t oN = in.take(sizeof(int));
+    const size_t inBytes = in.off;
+    const size_t oMatch = in.take((size_t)n * sizeof(int));  // the grid kernel clears a match array
+    const size_t oBest = in.take((size_t)M * 2 * sizeof(int));
+    ProjArgs A{};
+    A.B = 1; A.M = 1; A.kpStride = n;
+    A.g = GridDesc{KF->grid_cols, KF->grid_rows, KF->min_x, KF->min_y, KF->grid_inv_w, KF->grid_inv_h};
+    A.nnRatio = 1.0f;
+    A.nLevels = KF->n_levels;
+    int rc = proj_setup(m, A, in, inBytes + (size_t)M * 2 * sizeof(int) + 64, err);
+    if (rc != ORBFE_OK) return rc;
+    uint8_t* hp = static_cast<uint8_t*>(m.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(m.d);
+    memcpy(hp + oKp, KF->kp, (size_t)n * sizeof(orbfe_keypoint));
+    memcpy(hp + oDesc, KF->desc, (size_t)n * 32);
+    memcpy(hp + oPts, pts, (size_t)M * sizeof(orbfe_world_point));
+    memcpy(hp + oMpDesc, mpDesc, (size_t)M * 32);
+    memcpy(hp + oSf, KF->scale_factors, (size_t)KF->n_levels * sizeof(float));
+    memcpy(hp + oIs2, invLevelSigma2, (size_t)KF->n_levels * sizeof(float));
+    if (uRight) memcpy(hp + oUr, uRight, (size_t)n * sizeof(float));
+    memcpy(hp + oN, &n, sizeof(int));
+    MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
+    A.kp = reinterpret_cast<const orbfe_keypoint*>(dp + oKp);
+    A.desc = dp + oDesc;
+    A.nKp = reinterpret_cast<const int*>(dp + oN);
+    A.scaleFactors = reinterpret_cast<const float*>(dp + oSf);
+    A.matchOut = reinterpret_cast<int*>(dp + oMatch);
+    if (n <= kSortLds)
+        hipLaunchKernelGGL(proj_grid_kernel<true>, dim3(1), dim3(1024), 0, s, A);
+    else
+        hipLaunchKernelGGL(proj_grid_kernel<false>, dim3(1), dim3(1024), 0, s, A);
+    int* dBest = reinterpret_cast<int*>(dp + oBest);
+    hipLaunchKernelGGL(fuse_search_kernel, dim3((M + 255) / 256), dim3(256), 0, s, A, *F, th, M,
+                       reinterpret_cast<const orbfe_world_point*>(dp + oPts), dp + oMpDesc,
+                       reinterpret_cast<const float*>(dp + oIs2), uRight ? reinterpret_cast<const float*>(dp + oUr) : nullptr,
+                       dBest, dBest + M);
+    MCHK(hipGetLastError());
+    int* hBest = reinterpret_cast<int*>(hp + inBytes);
+    MCHK(hipMemcpyAsync(hBest, dBest, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    MCHK(hipStreamSynchronize(s));
+    memcpy(bestIdxOut, hBest, (size_t)M * sizeof(int));
+    memcpy(bestDistOut, hBest + M, (size_t)M * sizeof(int));
+    return ORBFE_OK;
 }
 
 }  // namespace orbfe

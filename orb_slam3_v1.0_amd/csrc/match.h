@@ -37,6 +37,10 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
                   int nF, const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation,
                   int* matchOut, int* nMatches, std::string& err);
 
+// the search part of ORBmatcher::Fuse (kernels_match_proj.hip)
+int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, const float* invLevelSigma2,
+                    const float* uRight, const orbfe_frustum* F, float th, int M, const orbfe_world_point* pts,
+                    const uint8_t* mpDesc, int* bestIdxOut, int* bestDistOut, std::string& err);
 // kernels_frustum.hip
 int frustum_validate(const orbfe_frustum* F);
 int frustum_launch(hipStream_t s, const orbfe_frustum* F, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,

@@ -661,6 +661,24 @@ int orbfe_project_map_points(orbfe_handle* h, const orbfe_frustum* frustum, int 
     return ORBFE_OK;
 }
 
+int orbfe_fuse_search(orbfe_handle* h, const orbfe_frame_view* KF, const float* inv_level_sigma2, const float* u_right,
+                      const orbfe_frustum* frustum, float th, int M, const orbfe_world_point* points, const uint8_t* mp_desc,
+                      int* best_idx_out, int* best_dist_out)
+{
+    if (!h || !KF || !inv_level_sigma2 || M < 0 || KF->n < 0 || (KF->n > 0 && (!KF->kp || !KF->desc || !KF->scale_factors)) ||
+        (M > 0 && (!points || !mp_desc || !best_idx_out || !best_dist_out)))
+        return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = fuse_search_run(h->match, h->stream, KF, inv_level_sigma2, u_right, frustum, th, M, points, mp_desc,
+                                   best_idx_out, best_dist_out, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
 struct orbfe_vocab {
     orbfe::Vocab* v;
     int device;

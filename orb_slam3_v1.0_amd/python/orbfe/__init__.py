@@ -62,7 +62,7 @@ SYMBOLS = [
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
     "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
-    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
@@ -122,6 +122,7 @@ def lib():
     L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
+    L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
     L.orbfe_vocab_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocab_destroy.argtypes = [vp]
     L.orbfe_vocab_destroy.restype = None
@@ -320,6 +321,20 @@ class ORBmatcher:
         self.e._chk(self.L.orbfe_project_map_points(self.e.h, C.byref(frustum), n, _p(points), _p(out), _p(xr)),
                     "orbfe_project_map_points")
         return out[:n], xr[:n]
+
+    def Fuse_search(self, kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
+        """The search part of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:678-836): (bestIdx, bestDist)
+        per map point; the caller applies bestDist <= TH_LOW and the graph edits."""
+        points = np.ascontiguousarray(points, WP_DTYPE)
+        mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+        is2 = np.ascontiguousarray(invLevelSigma2, np.float32)
+        ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        M = len(points)
+        bi = np.zeros(max(M, 1), np.int32)
+        bd = np.zeros(max(M, 1), np.int32)
+        self.e._chk(self.L.orbfe_fuse_search(self.e.h, C.byref(kf_view), _p(is2), _p(ur), C.byref(frustum), th, M,
+                                             _p(points), _p(mpDesc), _p(bi), _p(bd)), "orbfe_fuse_search")
+        return bi[:M], bd[:M]
 
     def isInFrustum_batch_device(self, frustum, n, d_points, d_out, d_proj_xr=None, stream=None):
         self.e._chk(self.L.orbfe_project_map_points_device(self.e.h, C.byref(frustum), n, d_points, d_out, d_proj_xr,

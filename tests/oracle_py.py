@@ -85,6 +85,8 @@ def lib():
         L.orc_spec_logf.restype = cf
         L.orc_is_in_frustum.argtypes = [C.POINTER(Frustum), ci, vp, vp, vp]
         L.orc_is_in_frustum.restype = None
+        L.orc_fuse_search.argtypes = [C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
+        L.orc_fuse_search.restype = None
         _lib = L
     return _lib
 
@@ -288,3 +290,15 @@ def is_in_frustum(frustum, points):
     xr = np.zeros(max(n, 1), np.float32)
     lib().orc_is_in_frustum(C.byref(frustum), n, _p(points), _p(out), _p(xr))
     return out[:n], xr[:n]
+
+
+def fuse_search(kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
+    points = np.ascontiguousarray(points, WP_DTYPE)
+    mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+    is2 = np.ascontiguousarray(invLevelSigma2, np.float32)
+    ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+    M = len(points)
+    bi = np.zeros(max(M, 1), np.int32)
+    bd = np.zeros(max(M, 1), np.int32)
+    lib().orc_fuse_search(C.byref(kf_view), _p(is2), _p(ur), C.byref(frustum), th, M, _p(points), _p(mpDesc), _p(bi), _p(bd))
+    return bi[:M], bd[:M]
