@@ -263,6 +263,30 @@ int orbfe_project_map_points_device(orbfe_handle *h, const orbfe_frustum *frustu
                                     const orbfe_world_point *d_points, orbfe_map_point *d_out,
                                     float *d_proj_xr, void *stream);
 
+/* what ORBmatcher::SearchForTriangulation derives from the two key-frame poses (src/ORBmatcher.cc:448-465) */
+typedef struct orbfe_tri_params {
+    float f12[9];           /* F12 = K1^-T [t12]x R12 K2^-1, row-major: the matrix Pinhole::epipolarConstrain
+                             * rebuilds for every pair (src/CameraModels/Pinhole.cpp:106-109) */
+    float ep_x, ep_y;       /* epipole: pKF2->mpCamera->project(T2w * Cw) (:451-454) */
+    int only_stereo;        /* bOnlyStereo */
+    int coarse;             /* bCoarse */
+    int check_orientation;  /* checkOrientation */
+} orbfe_tri_params;
+
+/* replaces ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse,
+ * checkOrientation) (src/ORBmatcher.cc:441-676; caller src/LocalMapping.cc:488), one pinhole camera per key
+ * frame.  The merge-walk over the two FeatureVectors (:489-617) is handed over as CSR groups in ascending
+ * NodeId order (as for orbfe_match_bow).  has_mp* [i] != 0 iff GetMapPoint(i) is set; stereo* [i] != 0 iff
+ * mvuRight[i] >= 0 (NULL == monocular); scale_factors2 = pKF2->mvScaleFactors (n_levels2 floats).
+ * matches12_out[i1] (n1 ints) = index in key frame 2 or -1, i.e. vMatchedPairs = {(i1, matches12_out[i1])} in
+ * ascending i1; *n_matches = the return value.  HOST pointers. */
+int orbfe_match_triangulation(orbfe_handle *h, int n_groups, const int *kf1_off, const int *kf1_idx,
+                              const int *kf2_off, const int *kf2_idx, int n1, const orbfe_keypoint *kp1,
+                              const uint8_t *desc1, const uint8_t *has_mp1, const uint8_t *stereo1, int n2,
+                              const orbfe_keypoint *kp2, const uint8_t *desc2, const uint8_t *has_mp2,
+                              const uint8_t *stereo2, const float *scale_factors2, int n_levels2,
+                              const orbfe_tri_params *params, int *matches12_out, int *n_matches);
+
 /* replaces the search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false)
  * (src/ORBmatcher.cc:678-836; callers src/LocalMapping.cc:822,852): per map point the projection into the
  * key frame, KeyFrame::IsInImage, PredictScale, KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:790-833), the

@@ -257,6 +257,102 @@ public:
     }
 };
 
+// ORBmatcher::SearchForTriangulation / ORBmatcher::Fuse (src/ORBmatcher.cc:441-676, 678-851): the data-parallel
+// search runs on the GPU, the std::map merge-walk and the map-point graph edits stay on the host.
+struct KeyFrameMatcher {
+    // src/ORBmatcher.cc:441-676.  `KF` needs: N, mvKeysUn, mFeatVec (std::map<NodeId, vector<unsigned>>), GetMapPoint(i),
+    // mvuRight, mvScaleFactors; descriptors through descOf(pKF) (N x 32 bytes).  F12 / ep are computed by the caller
+    // with the reference's own expressions (Pinhole.cpp:106-109, ORBmatcher.cc:451-454) and passed in `prm`.
+    template <class KeyFramePtr, class DescOf>
+    static int SearchForTriangulation(orbfe_handle* h, KeyFramePtr pKF1, KeyFramePtr pKF2, const orbfe_tri_params& prm,
+                                      std::vector<std::pair<size_t, size_t>>& vMatchedPairs, DescOf descOf)
+    {
+        std::vector<int> off1{0}, idx1, off2{0}, idx2;
+        auto f1 = pKF1->mFeatVec.begin(), f2 = pKF2->mFeatVec.begin();
+        while (f1 != pKF1->mFeatVec.end() && f2 != pKF2->mFeatVec.end()) {  // :489-617
+            if (f1->first == f2->first) {
+                idx1.insert(idx1.end(), f1->second.begin(), f1->second.end());
+                idx2.insert(idx2.end(), f2->second.begin(), f2->second.end());
+                off1.push_back((int)idx1.size());
+                off2.push_back((int)idx2.size());
+                ++f1;
+                ++f2;
+            } else if (f1->first < f2->first) {
+                f1 = pKF1->mFeatVec.lower_bound(f2->first);
+            } else {
+                f2 = pKF2->mFeatVec.lower_bound(f1->first);
+            }
+        }
+        const int n1 = pKF1->N, n2 = pKF2->N;
+        std::vector<uint8_t> has1(n1 > 0 ? n1 : 1), has2(n2 > 0 ? n2 : 1), st1(n1 > 0 ? n1 : 1), st2(n2 > 0 ? n2 : 1);
+        for (int i = 0; i < n1; i++) {
+            has1[i] = pKF1->GetMapPoint(i) ? 1 : 0;
+            st1[i] = pKF1->mvuRight[i] >= 0 ? 1 : 0;
+        }
+        for (int i = 0; i < n2; i++) {
+            has2[i] = pKF2->GetMapPoint(i) ? 1 : 0;
+            st2[i] = pKF2->mvuRight[i] >= 0 ? 1 : 0;
+        }
+        std::vector<int> m12(n1 > 0 ? n1 : 1);
+        int nmatches = 0;
+        orbfe_detail::check(orbfe_match_triangulation(
+            h, (int)off1.size() - 1, off1.data(), idx1.data(), off2.data(), idx2.data(), n1,
+            reinterpret_cast<const orbfe_keypoint*>(pKF1->mvKeysUn->data()), descOf(pKF1), has1.data(), st1.data(), n2,
+            reinterpret_cast<const orbfe_keypoint*>(pKF2->mvKeysUn->data()), descOf(pKF2), has2.data(), st2.data(),
+            pKF2->mvScaleFactors.data(), (int)pKF2->mvScaleFactors.size(), &prm, m12.data(), &nmatches), h,
+            "orbfe_match_triangulation");
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(nmatches);
+        for (int i = 0; i < n1; i++)
+            if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);  // :664-673
+        return nmatches;
+    }
+
+    // src/ORBmatcher.cc:678-851 (bRight == false).  The search result of every map point is computed first; the
+    // loop below then replays :699-849 in list order with the CURRENT graph state (isBad / IsInKeyFrame may have
+    // changed through an earlier Replace), exactly like the reference.  `frustum` carries the key frame's pose and
+    // pinhole intrinsics (GetPose / GetTranslationInverse), mbf, mfLogScaleFactor, mnScaleLevels, image bounds.
+    template <class KeyFramePtr, class MapPointPtr, class DescOfKF, class DescOfMP>
+    static int Fuse(orbfe_handle* h, KeyFramePtr pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th,
+                    const orbfe_frustum& frustum, const orbfe_frame_view& kfView, DescOfKF, DescOfMP descOfMP)
+    {
+        const int M = (int)vpMapPoints.size();
+        std::vector<orbfe_world_point> pts(M > 0 ? M : 1);
+        std::vector<uint8_t> mpd((size_t)(M > 0 ? M : 1) * 32);
+        for (int i = 0; i < M; i++) {
+            const auto& pMP = vpMapPoints[i];
+            orbfe_world_point& p = pts[i];
+            p = orbfe_world_point{0, 0, 0, 0, 0, 0, 0, 1};
+            if (!pMP) continue;
+            const auto P = pMP->GetWorldPos();
+            p = orbfe_world_point{P[0], P[1], P[2], pMP->mfMinDistance, pMP->mfMaxDistance, pMP->isBad() ? 1 : 0,
+                                  pMP->Observations(), pMP->IsInKeyFrame(pKF) ? 1 : 0};
+            std::memcpy(&mpd[(size_t)i * 32], descOfMP(pMP), 32);
+        }
+        std::vector<int> bestIdx(M > 0 ? M : 1), bestDist(M > 0 ? M : 1);
+        orbfe_detail::check(orbfe_fuse_search(h, &kfView, pKF->mvInvLevelSigma2.data(), pKF->mvuRight.data(), &frustum, th, M,
+                                              pts.data(), mpd.data(), bestIdx.data(), bestDist.data()), h, "orbfe_fuse_search");
+        int nFused = 0;
+        for (int i = 0; i < M; i++) {
+            const auto& pMP = vpMapPoints[i];
+            if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;  // :701-720, re-evaluated in order
+            if (bestDist[i] > ORBFE_TH_LOW) continue;                       // :829
+            auto pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx[i]);
+                pKF->AddMapPoint(pMP, bestIdx[i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+};
+
 // The isInFrustum loop of Tracking::SearchLocalPoints (src/Tracking.cc:1059-1077) for all local map points in one
 // launch.  `frustum` carries what Frame::isInFrustum reads from the frame (GetRcw / GetTcw / GetTwc, image bounds,
 // pinhole intrinsics, mbf, mfLogScaleFactor, mnScaleLevels); `MapPoint` needs GetWorldPos() (indexable [0..2]),

@@ -545,3 +545,96 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
     free(vIndices);
     free_grid(KF, g);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * SURVEY 8f row f2 (second half): ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:441-676), one
+ * pinhole camera per key frame (mpCamera2 == null).  The caller hands over what the function derives
+ * from the two poses with the reference's own expressions -- the epipole ep (:451-454) and the fundamental
+ * matrix F12 = K1^-T [t12]x R12 K2^-1 that Pinhole::epipolarConstrain rebuilds for every pair
+ * (src/CameraModels/Pinhole.cpp:106-109), row-major -- plus the FeatureVector merge-walk as CSR groups.
+ * hasMP* = "GetMapPoint(idx) != null", stereo* = "mvuRight[idx] >= 0" (NULL == monocular).
+ * This fork never sets vbMatched2 (:470,531), so key-frame-1 features choose independently.
+ * The per-pair float arithmetic follows SPEC DECISION S8 (left to right, no contraction).
+ * matches12Out[i1] = index in key frame 2 or -1; returns nmatches.
+ * ------------------------------------------------------------------------------------------ */
+int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const int *off2, const int *idx2v, int n1,
+                                 const orc_keypoint *kp1, const uint8_t *desc1, const uint8_t *hasMP1,
+                                 const uint8_t *stereo1, int n2, const orc_keypoint *kp2, const uint8_t *desc2,
+                                 const uint8_t *hasMP2, const uint8_t *stereo2, const float *scaleFactors2,
+                                 const float *F12, float epx, float epy, int bOnlyStereo, int bCoarse,
+                                 int checkOrientation, int *matches12Out)
+{
+    (void)n2;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12Out[i] = -1;
+    int *rotHist[HISTO_LENGTH];
+    int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
+        rotN[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int g = 0; g < G; g++) {
+        for (int i1 = off1[g]; i1 < off1[g + 1]; i1++) {
+            const int idx1 = idx1v[i1];
+            if (hasMP1[idx1]) continue; /* :506-509 */
+            const int bStereo1 = stereo1 && stereo1[idx1];
+            if (bOnlyStereo && !bStereo1) continue;
+            const orc_keypoint *k1 = &kp1[idx1];
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int i2 = off2[g]; i2 < off2[g + 1]; i2++) {
+                const int idx2 = idx2v[i2];
+                if (hasMP2[idx2]) continue; /* :531 (vbMatched2 is never set) */
+                const int bStereo2 = stereo2 && stereo2[idx2];
+                if (bOnlyStereo && !bStereo2) continue;
+                const int dist = orc_hamming(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+                if (dist > TH_LOW || dist > bestDist) continue; /* :545: ties replace the earlier one */
+                const orc_keypoint *k2 = &kp2[idx2];
+                if (!bStereo1 && !bStereo2) { /* :551-565 */
+                    const float distex = epx - k2->x, distey = epy - k2->y;
+                    const float err = distex * distex + distey * distey;
+                    if (err < 100 * scaleFactors2[k2->octave]) continue;
+                }
+                /* Pinhole::epipolarConstrain, src/CameraModels/Pinhole.cpp:111-125 */
+                const float a = (k1->x * F12[0] + k1->y * F12[3]) + F12[6];
+                const float b = (k1->x * F12[1] + k1->y * F12[4]) + F12[7];
+                const float c = (k1->x * F12[2] + k1->y * F12[5]) + F12[8];
+                const float num = (a * k2->x + b * k2->y) + c;
+                const float den = a * a + b * b;
+                int ok = 0;
+                if (den != 0) {
+                    const float dsqr = num * num / den;
+                    ok = dsqr < 3.84 * 1.0; /* float against a double constant */
+                }
+                if (bCoarse || ok) {
+                    bestIdx2 = idx2;
+                    bestDist = dist;
+                }
+            }
+            if (bestIdx2 >= 0) {
+                matches12Out[idx1] = bestIdx2;
+                nmatches++;
+                if (checkOrientation) {
+                    float rot = k1->angle - kp2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin][rotN[bin]++] = idx1;
+                }
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) {
+                matches12Out[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    return nmatches;
+}

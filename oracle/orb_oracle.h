@@ -151,6 +151,14 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
                      float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
                      int *bestDistOut);
 
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:441-676), pinhole, one camera per key frame */
+int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const int *off2, const int *idx2v, int n1,
+                                 const orc_keypoint *kp1, const uint8_t *desc1, const uint8_t *hasMP1,
+                                 const uint8_t *stereo1, int n2, const orc_keypoint *kp2, const uint8_t *desc2,
+                                 const uint8_t *hasMP2, const uint8_t *stereo2, const float *scaleFactors2,
+                                 const float *F12, float epx, float epy, int bOnlyStereo, int bCoarse,
+                                 int checkOrientation, int *matches12Out);
+
 /* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480): linear cell per kp or -1 */
 void orc_assign_grid(const orc_frame_view *F, int *cellOut);
 

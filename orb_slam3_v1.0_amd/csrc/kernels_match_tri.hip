@@ -1,0 +1,250 @@
+// kernels_match_tri.hip -- ORBmatcher::SearchForTriangulation on gfx950.
+//
+// Replaces src/ORBmatcher.cc:441-676 for one pinhole camera per key frame (callers src/LocalMapping.cc:488, up
+// to 30 neighbour key frames per new key frame) and Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:104-131).
+// This fork never sets vbMatched2, so every key-frame-1 feature picks its partner independently of the others:
+// one thread per feature of key frame 1 walks the features of key frame 2 that share its vocabulary node
+// (sequentially, so the "dist > bestDist -> continue" rule keeps the LAST candidate among equal distances, as in
+// the reference), then one block applies the rotation histogram (ComputeThreeMaxima).  Distances are __popcll
+// over 4 x 64-bit words; the geometric gates are SPEC DECISION S8 binary32 arithmetic.
+#include <algorithm>
+#include <cstring>
+
+#include "match_common.h"
+
+#pragma clang fp contract(off)
+
+namespace orbfe {
+
+namespace {
+
+struct TriArgs {
+    int nPos1;                    // entries of idx1 (features of key frame 1 that sit in a shared node)
+    const int* idx1;              // [nPos1]
+    const int* grp1;              // [nPos1] group of every entry
+    const int* off2;              // [G + 1]
+    const int* idx2;
+    const orbfe_keypoint* kp1;
+    const orbfe_keypoint* kp2;
+    const uint8_t* desc1;
+    const uint8_t* desc2;
+    const uint8_t* hasMP1;
+    const uint8_t* hasMP2;
+    const uint8_t* stereo1;       // or null
+    const uint8_t* stereo2;
+    const float* sf2;
+    float F12[9];
+    float epx, epy;
+    int onlyStereo, coarse, checkOrientation;
+    int n1;
+    int* match12;                 // [n1]
+    int* binOf;                   // [n1]
+    int* nMatches;
+};
+
+__global__ __launch_bounds__(256) void tri_match_kernel(TriArgs A)
+{
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= A.nPos1) return;
+    const int idx1 = A.idx1[pos];
+    if (A.hasMP1[idx1]) return;  // :506-509
+    const bool bStereo1 = A.stereo1 && A.stereo1[idx1];
+    if (A.onlyStereo && !bStereo1) return;
+    const orbfe_keypoint k1 = A.kp1[idx1];
+    unsigned long long d4[4];
+    const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.desc1 + (size_t)idx1 * 32);
+    d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
+    // epipolar line of k1 in image 2, Pinhole.cpp:112-114
+    const float a = (k1.x * A.F12[0] + k1.y * A.F12[3]) + A.F12[6];
+    const float b = (k1.x * A.F12[1] + k1.y * A.F12[4]) + A.F12[7];
+    const float c = (k1.x * A.F12[2] + k1.y * A.F12[5]) + A.F12[8];
+    const float den = a * a + b * b;
+    const int g = A.grp1[pos];
+    int bestDist = ORBFE_TH_LOW, bestIdx2 = -1;
+    for (int i2 = A.off2[g]; i2 < A.off2[g + 1]; i2++) {
+        const int idx2 = A.idx2[i2];
+        if (A.hasMP2[idx2]) continue;  // :531
+        const bool bStereo2 = A.stereo2 && A.stereo2[idx2];
+        if (A.onlyStereo && !bStereo2) continue;
+        const int dist = hamming256(reinterpret_cast<const uint2*>(A.desc2 + (size_t)idx2 * 32), d4);
+        if (dist > ORBFE_TH_LOW || dist > bestDist) continue;  // :545
+        const orbfe_keypoint k2 = A.kp2[idx2];
+        if (!bStereo1 && !bStereo2) {  // :551-565
+            const float distex = A.epx - k2.x, distey = A.epy - k2.y;
+            const float err = distex * distex + distey * distey;
+            if (err < 100 * A.sf2[k2.octave]) continue;
+        }
+        const float num = (a * k2.x + b * k2.y) + c;
+        bool ok = false;
+        if (den != 0) {
+            const float dsqr = num * num / den;
+            ok = (double)dsqr < 3.84 * 1.0;
+        }
+        if (A.coarse || ok) {
+            bestIdx2 = idx2;
+            bestDist = dist;
+        }
+    }
+    if (bestIdx2 >= 0) {
+        A.match12[idx1] = bestIdx2;
+        if (A.checkOrientation) {
+            float rot = k1.angle - A.kp2[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));
+            if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+            A.binOf[idx1] = bin;
+        }
+    }
+}
+
+// rotation-histogram filter (:633-661) + count; single block
+__global__ __launch_bounds__(256) void tri_finalize_kernel(TriArgs A)
+{
+    __shared__ int hist[ORBFE_HISTO_LENGTH];
+    __shared__ int sInd[3];
+    __shared__ int sCount;
+    const int tid = threadIdx.x;
+    if (tid < ORBFE_HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    int local = 0;
+    for (int j = tid; j < A.n1; j += blockDim.x)
+        if (A.match12[j] >= 0) {
+            local++;
+            if (A.checkOrientation) atomicAdd(&hist[A.binOf[j]], 1);
+        }
+    __syncthreads();
+    if (tid == 0) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        if (A.checkOrientation) {  // ComputeThreeMaxima :1328-1370
+            int max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < ORBFE_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        }
+        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+    }
+    __syncthreads();
+    if (A.checkOrientation) {
+        for (int j = tid; j < A.n1; j += blockDim.x)
+            if (A.match12[j] >= 0) {
+                const int bb = A.binOf[j];
+                if (bb != sInd[0] && bb != sInd[1] && bb != sInd[2]) {
+                    A.match12[j] = -1;
+                    local--;
+                }
+            }
+    }
+    if (local) atomicAdd(&sCount, local);
+    __syncthreads();
+    if (tid == 0) *A.nMatches = sCount;
+}
+
+}  // namespace
+
+int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* off1, const int* idx1, const int* off2,
+                            const int* idx2, int n1, const orbfe_keypoint* kp1, const uint8_t* desc1, const uint8_t* hasMP1,
+                            const uint8_t* stereo1, int n2, const orbfe_keypoint* kp2, const uint8_t* desc2,
+                            const uint8_t* hasMP2, const uint8_t* stereo2, const float* sf2, int nLevels2,
+                            const orbfe_tri_params* P, int* matches12, int* nMatches, std::string& err)
+{
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    *nMatches = 0;
+    if (G == 0 || n1 == 0 || n2 == 0) return ORBFE_OK;
+    const int nPos1 = off1[G], nPos2 = off2[G];
+    for (int g = 0; g < G; g++)
+        if (off1[g + 1] < off1[g] || off2[g + 1] < off2[g]) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < nPos1; i++)
+        if (idx1[i] < 0 || idx1[i] >= n1) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < nPos2; i++)
+        if (idx2[i] < 0 || idx2[i] >= n2) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < n2; i++)
+        if (kp2[i].octave < 0 || kp2[i].octave >= nLevels2) return ORBFE_ERR_INVALID_ARG;  // indexes mvScaleFactors
+    if (nPos1 == 0) return ORBFE_OK;
+
+    Carver in;
+    const size_t oIdx1 = in.take((size_t)nPos1 * sizeof(int));
+    const size_t oGrp1 = in.take((size_t)nPos1 * sizeof(int));
+    const size_t oOff2 = in.take((size_t)(G + 1) * sizeof(int));
+    const size_t oIdx2 = in.take((size_t)std::max(nPos2, 1) * sizeof(int));
+    const size_t oKp1 = in.take((size_t)n1 * sizeof(orbfe_keypoint));
+    const size_t oKp2 = in.take((size_t)n2 * sizeof(orbfe_keypoint));
+    const size_t oD1 = in.take((size_t)n1 * 32);
+    const size_t oD2 = in.take((size_t)n2 * 32);
+    const size_t oH1 = in.take((size_t)n1);
+    const size_t oH2 = in.take((size_t)n2);
+    const size_t oS1 = in.take((size_t)n1);
+    const size_t oS2 = in.take((size_t)n2);
+    const size_t oSf = in.take((size_t)nLevels2 * sizeof(float));
+    const size_t inBytes = in.off;
+    Carver sc = in;
+    const size_t oMatch = sc.take((size_t)n1 * sizeof(int));
+    const size_t oBin = sc.take((size_t)n1 * sizeof(int));
+    const size_t oNM = sc.take(sizeof(int));
+    int rc = ensure(m, sc.off, inBytes + (size_t)n1 * sizeof(int) + 256, err);
+    if (rc != ORBFE_OK) return rc;
+    uint8_t* hp = static_cast<uint8_t*>(m.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(m.d);
+    memcpy(hp + oIdx1, idx1, (size_t)nPos1 * sizeof(int));
+    int* grp = reinterpret_cast<int*>(hp + oGrp1);
+    for (int g = 0; g < G; g++)
+        for (int i = off1[g]; i < off1[g + 1]; i++) grp[i] = g;
+    memcpy(hp + oOff2, off2, (size_t)(G + 1) * sizeof(int));
+    memcpy(hp + oIdx2, idx2, (size_t)nPos2 * sizeof(int));
+    memcpy(hp + oKp1, kp1, (size_t)n1 * sizeof(orbfe_keypoint));
+    memcpy(hp + oKp2, kp2, (size_t)n2 * sizeof(orbfe_keypoint));
+    memcpy(hp + oD1, desc1, (size_t)n1 * 32);
+    memcpy(hp + oD2, desc2, (size_t)n2 * 32);
+    memcpy(hp + oH1, hasMP1, (size_t)n1);
+    memcpy(hp + oH2, hasMP2, (size_t)n2);
+    if (stereo1) memcpy(hp + oS1, stereo1, (size_t)n1);
+    if (stereo2) memcpy(hp + oS2, stereo2, (size_t)n2);
+    memcpy(hp + oSf, sf2, (size_t)nLevels2 * sizeof(float));
+    MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
+
+    TriArgs A{};
+    A.nPos1 = nPos1;
+    A.idx1 = reinterpret_cast<const int*>(dp + oIdx1);
+    A.grp1 = reinterpret_cast<const int*>(dp + oGrp1);
+    A.off2 = reinterpret_cast<const int*>(dp + oOff2);
+    A.idx2 = reinterpret_cast<const int*>(dp + oIdx2);
+    A.kp1 = reinterpret_cast<const orbfe_keypoint*>(dp + oKp1);
+    A.kp2 = reinterpret_cast<const orbfe_keypoint*>(dp + oKp2);
+    A.desc1 = dp + oD1;
+    A.desc2 = dp + oD2;
+    A.hasMP1 = dp + oH1;
+    A.hasMP2 = dp + oH2;
+    A.stereo1 = stereo1 ? dp + oS1 : nullptr;
+    A.stereo2 = stereo2 ? dp + oS2 : nullptr;
+    A.sf2 = reinterpret_cast<const float*>(dp + oSf);
+    for (int i = 0; i < 9; i++) A.F12[i] = P->f12[i];
+    A.epx = P->ep_x;
+    A.epy = P->ep_y;
+    A.onlyStereo = P->only_stereo;
+    A.coarse = P->coarse;
+    A.checkOrientation = P->check_orientation;
+    A.n1 = n1;
+    A.match12 = reinterpret_cast<int*>(dp + oMatch);
+    A.binOf = reinterpret_cast<int*>(dp + oBin);
+    A.nMatches = reinterpret_cast<int*>(dp + oNM);
+    const dim3 blk(256);
+    hipLaunchKernelGGL(fill_kernel, dim3((n1 + 255) / 256), blk, 0, s, A.match12, -1, (size_t)n1);
+    hipLaunchKernelGGL(tri_match_kernel, dim3((nPos1 + 255) / 256), blk, 0, s, A);
+    hipLaunchKernelGGL(tri_finalize_kernel, dim3(1), blk, 0, s, A);
+    MCHK(hipGetLastError());
+    int* hMatch = reinterpret_cast<int*>(hp + inBytes);
+    int* hNM = hMatch + n1;
+    MCHK(hipMemcpyAsync(hMatch, A.match12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, s));
+    MCHK(hipMemcpyAsync(hNM, A.nMatches, sizeof(int), hipMemcpyDeviceToHost, s));
+    MCHK(hipStreamSynchronize(s));
+    memcpy(matches12, hMatch, (size_t)n1 * sizeof(int));
+    *nMatches = *hNM;
+    return ORBFE_OK;
+}
+
+}  // namespace orbfe

@@ -41,6 +41,12 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
 int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, const float* invLevelSigma2,
                     const float* uRight, const orbfe_frustum* F, float th, int M, const orbfe_world_point* pts,
                     const uint8_t* mpDesc, int* bestIdxOut, int* bestDistOut, std::string& err);
+// kernels_match_tri.hip
+int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* off1, const int* idx1, const int* off2,
+                            const int* idx2, int n1, const orbfe_keypoint* kp1, const uint8_t* desc1, const uint8_t* hasMP1,
+                            const uint8_t* stereo1, int n2, const orbfe_keypoint* kp2, const uint8_t* desc2,
+                            const uint8_t* hasMP2, const uint8_t* stereo2, const float* sf2, int nLevels2,
+                            const orbfe_tri_params* P, int* matches12, int* nMatches, std::string& err);
 // kernels_frustum.hip
 int frustum_validate(const orbfe_frustum* F);
 int frustum_launch(hipStream_t s, const orbfe_frustum* F, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,

@@ -679,6 +679,28 @@ int orbfe_fuse_search(orbfe_handle* h, const orbfe_frame_view* KF, const float* 
     return rc;
 }
 
+int orbfe_match_triangulation(orbfe_handle* h, int n_groups, const int* kf1_off, const int* kf1_idx, const int* kf2_off,
+                              const int* kf2_idx, int n1, const orbfe_keypoint* kp1, const uint8_t* desc1,
+                              const uint8_t* has_mp1, const uint8_t* stereo1, int n2, const orbfe_keypoint* kp2,
+                              const uint8_t* desc2, const uint8_t* has_mp2, const uint8_t* stereo2,
+                              const float* scale_factors2, int n_levels2, const orbfe_tri_params* params,
+                              int* matches12_out, int* n_matches)
+{
+    if (!h || !params || !n_matches || n_groups < 0 || n1 < 0 || n2 < 0 || n_levels2 < 1 || !scale_factors2 ||
+        (n_groups > 0 && (!kf1_off || !kf2_off)) || (n1 > 0 && (!kp1 || !desc1 || !has_mp1 || !matches12_out)) ||
+        (n2 > 0 && (!kp2 || !desc2 || !has_mp2)))
+        return ORBFE_ERR_INVALID_ARG;
+    if (n_groups > 0 && ((kf1_off[n_groups] > 0 && !kf1_idx) || (kf2_off[n_groups] > 0 && !kf2_idx))) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = match_triangulation_run(h->match, h->stream, n_groups, kf1_off, kf1_idx, kf2_off, kf2_idx, n1, kp1, desc1,
+                                           has_mp1, stereo1, n2, kp2, desc2, has_mp2, stereo2, scale_factors2, n_levels2,
+                                           params, matches12_out, n_matches, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
 struct orbfe_vocab {
     orbfe::Vocab* v;
     int device;

@@ -48,6 +48,12 @@ class Frustum(C.Structure):
                 ("n_levels", C.c_int), ("camera_model", C.c_int)]
 
 
+class TriParams(C.Structure):
+    """orbfe_tri_params: F12, epipole and the three flags of SearchForTriangulation."""
+    _fields_ = [("f12", C.c_float * 9), ("ep_x", C.c_float), ("ep_y", C.c_float), ("only_stereo", C.c_int),
+                ("coarse", C.c_int), ("check_orientation", C.c_int)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int), ("kp", C.c_void_p), ("desc", C.c_void_p), ("grid_cols", C.c_int),
                 ("grid_rows", C.c_int), ("min_x", C.c_float), ("min_y", C.c_float),
@@ -62,7 +68,7 @@ SYMBOLS = [
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
     "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
-    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_match_triangulation", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
@@ -123,6 +129,8 @@ def lib():
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
+    L.orbfe_match_triangulation.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci,
+                                            C.POINTER(TriParams), vp, vp]
     L.orbfe_vocab_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocab_destroy.argtypes = [vp]
     L.orbfe_vocab_destroy.restype = None
@@ -321,6 +329,29 @@ class ORBmatcher:
         self.e._chk(self.L.orbfe_project_map_points(self.e.h, C.byref(frustum), n, _p(points), _p(out), _p(xr)),
                     "orbfe_project_map_points")
         return out[:n], xr[:n]
+
+    def SearchForTriangulation(self, off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1, kp2, desc2, hasMP2, stereo2,
+                               scaleFactors2, F12, ep, bOnlyStereo=False, bCoarse=False, checkOrientation=True):
+        """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:441-676): returns (nmatches, vMatches12)."""
+        a32 = lambda v: np.ascontiguousarray(v, np.int32)
+        u8 = lambda v: None if v is None else np.ascontiguousarray(v, np.uint8)
+        off1, idx1, off2, idx2 = a32(off1), a32(idx1), a32(off2), a32(idx2)
+        kp1, kp2 = np.ascontiguousarray(kp1, KP_DTYPE), np.ascontiguousarray(kp2, KP_DTYPE)
+        desc1, desc2 = u8(desc1), u8(desc2)
+        h1, h2, s1, s2 = u8(hasMP1), u8(hasMP2), u8(stereo1), u8(stereo2)
+        sf = np.ascontiguousarray(scaleFactors2, np.float32)
+        P = TriParams()
+        for i, v in enumerate(np.asarray(F12, np.float32).reshape(-1)):
+            P.f12[i] = float(v)
+        P.ep_x, P.ep_y = float(ep[0]), float(ep[1])
+        P.only_stereo, P.coarse, P.check_orientation = int(bOnlyStereo), int(bCoarse), int(checkOrientation)
+        out = np.full(max(len(kp1), 1), -1, np.int32)
+        n = C.c_int()
+        self.e._chk(self.L.orbfe_match_triangulation(self.e.h, len(off1) - 1, _p(off1), _p(idx1), _p(off2), _p(idx2), len(kp1),
+                                                     _p(kp1), _p(desc1), _p(h1), _p(s1), len(kp2), _p(kp2), _p(desc2), _p(h2),
+                                                     _p(s2), _p(sf), len(sf), C.byref(P), _p(out), C.byref(n)),
+                    "orbfe_match_triangulation")
+        return n.value, out[:len(kp1)].copy()
 
     def Fuse_search(self, kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
         """The search part of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:678-836): (bestIdx, bestDist)

@@ -87,6 +87,8 @@ def lib():
         L.orc_is_in_frustum.restype = None
         L.orc_fuse_search.argtypes = [C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
         L.orc_fuse_search.restype = None
+        L.orc_search_for_triangulation.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, cf,
+                                                   ci, ci, ci, vp]
         _lib = L
     return _lib
 
@@ -302,3 +304,20 @@ def fuse_search(kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
     bd = np.zeros(max(M, 1), np.int32)
     lib().orc_fuse_search(C.byref(kf_view), _p(is2), _p(ur), C.byref(frustum), th, M, _p(points), _p(mpDesc), _p(bi), _p(bd))
     return bi[:M], bd[:M]
+
+
+def search_for_triangulation(off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1, kp2, desc2, hasMP2, stereo2,
+                             scaleFactors2, F12, ep, bOnlyStereo=False, bCoarse=False, checkOrientation=True):
+    a32 = lambda v: np.ascontiguousarray(v, np.int32)
+    u8 = lambda v: None if v is None else np.ascontiguousarray(v, np.uint8)
+    off1, idx1, off2, idx2 = a32(off1), a32(idx1), a32(off2), a32(idx2)
+    kp1, kp2 = np.ascontiguousarray(kp1, KP_DTYPE), np.ascontiguousarray(kp2, KP_DTYPE)
+    desc1, desc2, h1, h2, s1, s2 = u8(desc1), u8(desc2), u8(hasMP1), u8(hasMP2), u8(stereo1), u8(stereo2)
+    sf = np.ascontiguousarray(scaleFactors2, np.float32)
+    F = np.ascontiguousarray(np.asarray(F12, np.float32).reshape(-1))
+    out = np.full(max(len(kp1), 1), -1, np.int32)
+    n = lib().orc_search_for_triangulation(len(off1) - 1, _p(off1), _p(idx1), _p(off2), _p(idx2), len(kp1), _p(kp1),
+                                           _p(desc1), _p(h1), _p(s1), len(kp2), _p(kp2), _p(desc2), _p(h2), _p(s2), _p(sf),
+                                           _p(F), float(np.float32(ep[0])), float(np.float32(ep[1])), int(bOnlyStereo),
+                                           int(bCoarse), int(checkOrientation), _p(out))
+    return n, out[:len(kp1)].copy()
