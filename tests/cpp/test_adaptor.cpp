@@ -1,6 +1,7 @@
 // Drives include/orbfe_adaptor.hpp the way src/Frame.cc:178-189 and src/Tracking.cc:1115 drive the
 // reference classes, with light mock Frame / MapPoint types that carry the members those functions read.
 //   usage: test_adaptor <W> <H> <gray.raw> <mps.bin> <M> <out.bin> [<voc.txt> <bow_out.txt>]
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -21,6 +22,37 @@ struct MapPoint {
     uint8_t desc[32];
     bool isBad() const { return bad; }
     int Observations() const { return obs; }
+};
+
+struct KeyFrame;
+struct MapPoint3D {  // the MapPoint members ORBmatcher::Fuse touches
+    float wp[3] = {0.f, 0.f, 1.f};
+    float mfMinDistance = 0.1f, mfMaxDistance = 100.f;
+    uint8_t desc[32];
+    bool bad = false;
+    int obs = 1;
+    std::vector<const KeyFrame*> inKF;
+    const float* GetWorldPos() const { return wp; }
+    bool isBad() const { return bad; }
+    int Observations() const { return obs; }
+    bool IsInKeyFrame(const std::shared_ptr<KeyFrame>& kf) const
+    {
+        for (auto k : inKF) if (k == kf.get()) return true;
+        return false;
+    }
+    void AddObservation(const std::shared_ptr<KeyFrame>& kf, size_t) { inKF.push_back(kf.get()); obs++; }
+    void Replace(const std::shared_ptr<MapPoint3D>& other) { bad = true; other->obs += obs; }
+};
+
+struct KeyFrame {
+    int N = 0;
+    std::shared_ptr<std::vector<KeyPoint>> mvKeysUn;
+    std::vector<uint8_t> mDescriptors;
+    std::map<unsigned, std::vector<unsigned>> mFeatVec;
+    std::vector<std::shared_ptr<MapPoint3D>> mvpMapPoints;
+    std::vector<float> mvuRight, mvScaleFactors, mvInvLevelSigma2;
+    std::shared_ptr<MapPoint3D> GetMapPoint(size_t i) const { return mvpMapPoints[i]; }
+    void AddMapPoint(const std::shared_ptr<MapPoint3D>& mp, size_t i) { mvpMapPoints[i] = mp; }
 };
 
 struct Frame {
@@ -124,6 +156,50 @@ int main(int argc, char** argv)
         long lvlSum = 0;
         for (auto& mp : cloud) if (mp->mbTrackInView) lvlSum += mp->mnTrackScaleLevel;
         std::printf("frustum nToMatch=%d levelSum=%ld\n", nToMatch, lvlSum);
+    }
+    {  // LocalMapping::CreateNewMapPoints / SearchInNeighbors: key frame against itself
+        auto kf = std::make_shared<KeyFrame>();
+        kf->N = n;
+        kf->mvKeysUn = keys;
+        kf->mDescriptors = desc;
+        kf->mvpMapPoints.assign(n, nullptr);
+        kf->mvuRight.assign(n, -1.f);
+        kf->mvScaleFactors = ex.GetScaleFactors();
+        kf->mvInvLevelSigma2 = ex.GetInverseScaleSigmaSquares();
+        for (int i = 0; i < n; i++) kf->mFeatVec[(unsigned)(i % 50)].push_back((unsigned)i);
+        orbfe_tri_params tp{};
+        tp.ep_x = -1e4f; tp.ep_y = 0.f; tp.coarse = 1; tp.check_orientation = 1;
+        std::vector<std::pair<size_t, size_t>> pairs;
+        const int nt = KeyFrameMatcher::SearchForTriangulation(ex.handle(), kf, kf, tp, pairs,
+                                                               [](const std::shared_ptr<KeyFrame>& k) { return k->mDescriptors.data(); });
+        size_t self = 0;
+        for (auto& pr : pairs) self += pr.first == pr.second;
+        // Fuse: map points sitting exactly on every 5th keypoint (identity pose, pinhole), descriptor copied
+        orbfe_frustum fr{};
+        fr.rcw[0] = fr.rcw[4] = fr.rcw[8] = 1.0f;
+        fr.min_x = 0.f; fr.max_x = (float)W; fr.min_y = 0.f; fr.max_y = (float)H;
+        fr.fx = fr.fy = 400.f; fr.cx = 0.5f * (float)W; fr.cy = 0.5f * (float)H;
+        fr.mbf = 40.f; fr.log_scale_factor = 0.18232156f; fr.n_levels = ex.GetLevels(); fr.camera_model = ORBFE_CAMERA_PINHOLE;
+        std::vector<std::shared_ptr<MapPoint3D>> mpts;
+        for (int i = 0; i < n; i += 5) {
+            auto mp = std::make_shared<MapPoint3D>();
+            const float z = 4.0f;
+            mp->wp[0] = ((*keys)[i].pt.x - fr.cx) / fr.fx * z;
+            mp->wp[1] = ((*keys)[i].pt.y - fr.cy) / fr.fy * z;
+            mp->wp[2] = z;
+            mp->mfMaxDistance = 5.0f * std::pow(1.2f, (float)(*keys)[i].octave);
+            mp->mfMinDistance = 0.05f;
+            std::memcpy(mp->desc, &desc[(size_t)i * 32], 32);
+            mpts.push_back(mp);
+        }
+        orbfe_frame_view kv{};
+        kv.n = n; kv.kp = reinterpret_cast<const orbfe_keypoint*>(keys->data()); kv.desc = desc.data();
+        kv.grid_cols = 64; kv.grid_rows = 48; kv.min_x = 0.f; kv.min_y = 0.f;
+        kv.grid_inv_w = 64.f / (float)W; kv.grid_inv_h = 48.f / (float)H;
+        kv.n_levels = ex.GetLevels(); kv.scale_factors = kf->mvScaleFactors.data();
+        const int nf = KeyFrameMatcher::Fuse(ex.handle(), kf, mpts, 3.0f, fr, kv, 0,
+                                             [](const std::shared_ptr<MapPoint3D>& m) { return m->desc; });
+        std::printf("triangulation n=%d self=%zu fuse=%d of %zu\n", nt, self, nf, mpts.size());
     }
     std::printf("adaptor ok: %d keypoints, %d matches, levels=%d scale=%g\n", n, nm, ex.GetLevels(), ex.GetScaleFactor());
     return 0;

@@ -80,3 +80,15 @@ def test_adaptor_matches_oracle(built, tmp_path):
     assert got_b == list(rb.items())
     got_f = {int(l.split()[0]): [int(t) for t in l.split()[2:]] for l in lines[1 + nb:1 + nb + nf]}
     assert got_f == rf
+    # KeyFrameMatcher::SearchForTriangulation (key frame against itself, bCoarse) == the oracle on the same groups
+    n_kp = len(kp_r)
+    groups = [np.arange(g, n_kp, 50) for g in range(min(50, n_kp))]
+    off = np.concatenate([[0], np.cumsum([len(g) for g in groups])])
+    idx = np.concatenate(groups)
+    z8 = np.zeros(n_kp, np.uint8)
+    nt, m12 = O.search_for_triangulation(off, idx, off, idx, kp_r, desc_r, z8, None, kp_r, desc_r, z8, None, e.scaleFactors,
+                                         np.zeros(9, np.float32), (-1e4, 0.0), False, True, True)
+    import re
+    mt = re.search(r"triangulation n=(\d+) self=(\d+) fuse=(\d+) of (\d+)", stdout)
+    assert mt and int(mt.group(1)) == nt and int(mt.group(2)) == int((m12 == np.arange(n_kp)).sum())
+    assert int(mt.group(3)) > int(mt.group(4)) // 2  # most on-keypoint map points fuse
