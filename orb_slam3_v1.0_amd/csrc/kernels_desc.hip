@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
                                                            const uint32_t* __restrict__ lvlKp,
                                                            orbfe_keypoint* __restrict__ kpOut,
                                                            uint8_t* __restrict__ descOut, int* __restrict__ nOut,
-                                                           int* __restrict__ perLevelOut)
+                                                           int* __restrict__ perLevelOut, int* __restrict__ statusOut)
 {
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
         nOut[f] = total;
         if (perLevelOut)
             for (int q = 0; q < nL; q++) perLevelOut[(size_t)f * nL + q] = (int)cnt[q * kCntWords + kCntKp];
+        if (statusOut) {  // device-side guard flags of all levels, so the host path needs no copy of the counters
+            uint32_t st = 0;
+            for (int q = 0; q < nL; q++) st |= cnt[q * kCntWords + kCntStatus];
+            statusOut[f] = (int)st;
+        }
     }
     if (!found) return;
 
@@ -153,12 +158,12 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
 void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const PipelineDesc* dP, const uint8_t* gray0,
                          size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws, const uint32_t* counters,
                          const uint32_t* lvlKp, orbfe_keypoint* kpOut, uint8_t* descOut, int* nOut,
-                         int* perLevelOut)
+                         int* perLevelOut, int* statusOut)
 {
     dim3 block(256);
     dim3 grid(frames, (kpCapFrame + 3) / 4);
     hipLaunchKernelGGL(orient_brief_kernel, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch, ws,
-                       counters, lvlKp, kpOut, descOut, nOut, perLevelOut);
+                       counters, lvlKp, kpOut, descOut, nOut, perLevelOut, statusOut);
 }
 
 }  // namespace orbfe

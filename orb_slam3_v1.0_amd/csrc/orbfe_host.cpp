@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -59,15 +60,24 @@ struct orbfe_handle {
     uint8_t* dIn = nullptr;
     int dInPitch = 0;
     uint8_t* hIn = nullptr;         // pinned
+    // results of the host-pointer API: ONE device block [n | status | per-level | keypoints | descriptors] with a
+    // pinned mirror of the same layout, so a full batch comes back in a single D2H copy
+    uint8_t* dOutBlock = nullptr;
+    uint8_t* hOutBlock = nullptr;   // pinned
+    size_t outBlockBytes = 0, offStatus = 0, offPer = 0, offKp = 0, offDesc = 0;
     orbfe_keypoint* dKp = nullptr;
     uint8_t* dDesc = nullptr;
     int* dN = nullptr;
+    int* dStatus = nullptr;
     int* dPer = nullptr;
-    orbfe_keypoint* hKp = nullptr;  // pinned
+    orbfe_keypoint* hKp = nullptr;
     uint8_t* hDesc = nullptr;
     int* hN = nullptr;
+    int* hStatus = nullptr;
     int* hPer = nullptr;
-    uint32_t* hCounters = nullptr;  // pinned copy for status checks
+    // the whole host-API call (H2D, kernel chain, D2H) as a captured hipGraph per batch size (latency path)
+    std::map<int, hipGraphExec_t> graphs;
+    bool useGraph = true;
 
     hipStream_t stream = nullptr;
     bool timing = false;
@@ -123,11 +133,13 @@ void destroy_impl(orbfe_handle* h)
         for (auto& e : set)
             if (e) (void)hipEventDestroy(e);
     match_scratch_free(h->match);
+    for (auto& g : h->graphs)
+        if (g.second) (void)hipGraphExecDestroy(g.second);
     void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTileRows, h->dQtScratch, h->dTabs,
-                     h->dSf, h->dIn, h->dKp, h->dDesc, h->dN, h->dPer};
+                     h->dSf, h->dIn, h->dOutBlock};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
-    void* hptrs[] = {h->hIn, h->hKp, h->hDesc, h->hN, h->hPer, h->hCounters};
+    void* hptrs[] = {h->hIn, h->hOutBlock};
     for (void* p : hptrs)
         if (p) (void)hipHostFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -313,15 +325,29 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     const size_t cap = (size_t)P.kpCapFrame;
     CREATE_CHK(hipMalloc(&h->dIn, inFrame * B));
     CREATE_CHK(hipHostMalloc(&h->hIn, inFrame * B));
-    CREATE_CHK(hipMalloc(&h->dKp, B * cap * sizeof(orbfe_keypoint)));
-    CREATE_CHK(hipMalloc(&h->dDesc, B * cap * ORBFE_DESC_BYTES));
-    CREATE_CHK(hipMalloc(&h->dN, B * sizeof(int)));
-    CREATE_CHK(hipMalloc(&h->dPer, B * nL * sizeof(int)));
-    CREATE_CHK(hipHostMalloc(&h->hKp, B * cap * sizeof(orbfe_keypoint)));
-    CREATE_CHK(hipHostMalloc(&h->hDesc, B * cap * ORBFE_DESC_BYTES));
-    CREATE_CHK(hipHostMalloc(&h->hN, B * sizeof(int)));
-    CREATE_CHK(hipHostMalloc(&h->hPer, B * nL * sizeof(int)));
-    CREATE_CHK(hipHostMalloc(&h->hCounters, B * nL * kCntWords * sizeof(uint32_t)));
+    {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+        take(B * sizeof(int));  // n at offset 0
+        h->offStatus = take(B * sizeof(int));
+        h->offPer = take(B * nL * sizeof(int));
+        h->offKp = take(B * cap * sizeof(orbfe_keypoint));
+        h->offDesc = take(B * cap * ORBFE_DESC_BYTES);
+        h->outBlockBytes = off;
+    }
+    CREATE_CHK(hipMalloc(&h->dOutBlock, h->outBlockBytes));
+    CREATE_CHK(hipHostMalloc(&h->hOutBlock, h->outBlockBytes));
+    h->dN = reinterpret_cast<int*>(h->dOutBlock);
+    h->dStatus = reinterpret_cast<int*>(h->dOutBlock + h->offStatus);
+    h->dPer = reinterpret_cast<int*>(h->dOutBlock + h->offPer);
+    h->dKp = reinterpret_cast<orbfe_keypoint*>(h->dOutBlock + h->offKp);
+    h->dDesc = h->dOutBlock + h->offDesc;
+    h->hN = reinterpret_cast<int*>(h->hOutBlock);
+    h->hStatus = reinterpret_cast<int*>(h->hOutBlock + h->offStatus);
+    h->hPer = reinterpret_cast<int*>(h->hOutBlock + h->offPer);
+    h->hKp = reinterpret_cast<orbfe_keypoint*>(h->hOutBlock + h->offKp);
+    h->hDesc = h->hOutBlock + h->offDesc;
+    h->useGraph = getenv("ORBFE_NO_GRAPH") == nullptr;
     for (auto& set : h->ev)
         for (auto& e : set) CREATE_CHK(hipEventCreate(&e));
 #undef CREATE_CHK
@@ -389,9 +415,20 @@ int orbfe_get_stage_ms(orbfe_handle* h, float ms[ORBFE_NUM_STAGES], int* n_calls
     return ORBFE_OK;
 }
 
+static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_stride, int pitch, int batch,
+                         orbfe_keypoint* d_kp, uint8_t* d_desc, int* d_n, int* d_per, int* d_status, void* stream_);
+
 int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t frame_stride, int pitch,
                                int batch, orbfe_keypoint* d_kp, uint8_t* d_desc, int* d_n, int* d_per,
                                void* stream_)
+{
+    return extract_chain(h, d_gray, frame_stride, pitch, batch, d_kp, d_desc, d_n, d_per, nullptr, stream_);
+}
+
+}  // extern "C"
+
+static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_stride, int pitch, int batch,
+                         orbfe_keypoint* d_kp, uint8_t* d_desc, int* d_n, int* d_per, int* d_status, void* stream_)
 {
     if (!h || !d_gray || !d_kp || !d_desc || !d_n) return ORBFE_ERR_INVALID_ARG;
     if (batch < 1 || batch > h->maxBatch || pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
@@ -429,7 +466,7 @@ int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t fr
                     pitch, h->ws, h->dTileRows, h->dQtScratch);
     if (ev) HIPCHK(h, hipEventRecord(ev[3], s));
     launch_orient_brief(s, batch, P.kpCapFrame, h->dP, d_gray, frame_stride, pitch, h->ws, h->dCounters, h->dLvlKp,
-                        d_kp, d_desc, d_n, d_per);
+                        d_kp, d_desc, d_n, d_per, d_status);
     if (ev) HIPCHK(h, hipEventRecord(ev[4], s));
     HIPCHK(h, hipGetLastError());
     h->lastGray = d_gray;
@@ -439,18 +476,39 @@ int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t fr
     return ORBFE_OK;
 }
 
+extern "C" {
+
 static int check_device_flags(orbfe_handle* h, int batch)
 {
-    // caller has synchronised the stream; hCounters holds the counters of the call
-    const int nL = h->nLevels;
-    for (int i = 0; i < batch * nL; i++)
-        if (h->hCounters[(size_t)i * kCntWords + kCntStatus]) {
+    // caller has synchronised the stream; hStatus holds the OR of the per-level guard flags of every frame
+    for (int b = 0; b < batch; b++)
+        if (h->hStatus[b]) {
             char buf[128];
-            snprintf(buf, sizeof buf, "device guard flags 0x%x at frame %d level %d",
-                     h->hCounters[(size_t)i * kCntWords + kCntStatus], i / nL, i % nL);
+            snprintf(buf, sizeof buf, "device guard flags 0x%x at frame %d", (unsigned)h->hStatus[b], b);
             h->err = buf;
             return ORBFE_ERR_INTERNAL;
         }
+    return ORBFE_OK;
+}
+
+// H2D of the staged frames, kernel chain, D2H of the result block (one copy for a full batch)
+static int extract_host_enqueue(orbfe_handle* h, int batch, hipStream_t s)
+{
+    const int nL = h->nLevels;
+    const size_t inFrame = (size_t)h->dInPitch * h->prm.image_height;
+    const size_t cap = (size_t)h->P.kpCapFrame;
+    HIPCHK(h, hipMemcpyAsync(h->dIn, h->hIn, inFrame * batch, hipMemcpyHostToDevice, s));
+    const int rc = extract_chain(h, h->dIn, inFrame, h->dInPitch, batch, h->dKp, h->dDesc, h->dN, h->dPer, h->dStatus, s);
+    if (rc != ORBFE_OK) return rc;
+    if (batch == h->maxBatch) {
+        HIPCHK(h, hipMemcpyAsync(h->hOutBlock, h->dOutBlock, h->outBlockBytes, hipMemcpyDeviceToHost, s));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->hN, h->dN, batch * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->hStatus, h->dStatus, batch * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->hPer, h->dPer, (size_t)batch * nL * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->hKp, h->dKp, batch * cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->hDesc, h->dDesc, batch * cap * ORBFE_DESC_BYTES, hipMemcpyDeviceToHost, s));
+    }
     return ORBFE_OK;
 }
 
@@ -469,19 +527,41 @@ int orbfe_extract_batch(orbfe_handle* h, const uint8_t* const* grays, int pitch,
             memcpy(h->hIn + b * inFrame + (size_t)y * h->dInPitch, grays[b] + (size_t)y * pitch, (size_t)W);
     }
     hipStream_t s = h->stream;
-    HIPCHK(h, hipMemcpyAsync(h->dIn, h->hIn, inFrame * batch, hipMemcpyHostToDevice, s));
-    int rc = orbfe_extract_batch_device(h, h->dIn, inFrame, h->dInPitch, batch, h->dKp, h->dDesc, h->dN, h->dPer, s);
-    if (rc != ORBFE_OK) return rc;
-    const size_t cap = (size_t)h->P.kpCapFrame;
-    HIPCHK(h, hipMemcpyAsync(h->hN, h->dN, batch * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->hPer, h->dPer, (size_t)batch * nL * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->hKp, h->dKp, batch * cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->hDesc, h->dDesc, batch * cap * ORBFE_DESC_BYTES, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->hCounters, h->dCounters, (size_t)batch * nL * kCntWords * sizeof(uint32_t),
-                             hipMemcpyDeviceToHost, s));
+    int rc;
+    if (h->useGraph && !h->timing) {
+        // every pointer of the call is owned by the handle, so the enqueue sequence is captured once per batch
+        // size and replayed with a single hipGraphLaunch (11 launches + 2..6 copies otherwise)
+        hipGraphExec_t& exec = h->graphs[batch];
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = extract_host_enqueue(h, batch, s);
+            const hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (rc != ORBFE_OK || ec != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                h->graphs.erase(batch);
+                h->useGraph = false;  // fall back to plain launches for the lifetime of the handle
+                (void)hipGetLastError();
+            } else {
+                const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ei != hipSuccess) {
+                    h->graphs.erase(batch);
+                    h->useGraph = false;
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        if (h->useGraph) HIPCHK(h, hipGraphLaunch(h->graphs[batch], s));
+    }
+    if (!h->useGraph || h->timing) {
+        rc = extract_host_enqueue(h, batch, s);
+        if (rc != ORBFE_OK) return rc;
+    }
     HIPCHK(h, hipStreamSynchronize(s));
     rc = check_device_flags(h, batch);
     if (rc != ORBFE_OK) return rc;
+    const size_t cap = (size_t)h->P.kpCapFrame;
     for (int b = 0; b < batch; b++) {
         const int n = h->hN[b];
         n_out[b] = n;
