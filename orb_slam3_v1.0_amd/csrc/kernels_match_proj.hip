@@ -85,7 +85,7 @@ struct ProjArgs {
     int* colStart;                // [B][tabLevels][cols*rows + 1]: first storage slot of (level, cell v = cx*rows + cy)
     int tabLevels;                // min(nLevels, 32)
     int* cnt;                     // [B][M] number of candidates (dist < 256) per map point
-    uint32_t* topk;               // [B][kTopK][M] sorted smallest keys (entry-major: coalesced per sweep)
+    uint32_t* topk;               // [B][M][kTopK] sorted smallest keys (one 64-byte line per map point)
     int* claimG;                  // [B][kpStride] fallback claim table (frames that do not fit the LDS image)
     int* perm;                    // [B][M] map points ordered by (level, tile): work assignment of the top-K pass
     int* dbg;                     // [B][4] diagnostics: sweeps, cooperative rescans, -, -
@@ -415,8 +415,11 @@ __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
         else total = topk_scan<false>(A, w, cs, tabStride, rec, descS, &S, segBase, d0, d1, d2, d3, keys);
     }
     A.cnt[(size_t)f * A.M + i] = total;
+    // map-point-major: the 16 keys of one map point are one 64-byte line (i is a permuted index: entry-major
+    // 4-byte stores would dirty 16 different sectors per map point)
+    uint4* dst = reinterpret_cast<uint4*>(A.topk + ((size_t)f * A.M + i) * kTopK);
 #pragma unroll
-    for (int t = 0; t < kTopK; t++) A.topk[((size_t)f * kTopK + t) * A.M + i] = keys[t];
+    for (int t = 0; t < kTopK / 4; t++) dst[t] = make_uint4(keys[4 * t], keys[4 * t + 1], keys[4 * t + 2], keys[4 * t + 3]);
 }
 
 // One persistent block per frame, one THREAD per map point, chunks of 1024 map points in index order.
@@ -534,8 +537,12 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
             c = A.cnt[(size_t)f * M + i];
             obs = mps[i].observations;
             if (c > 0) {
+                const uint4* src = reinterpret_cast<const uint4*>(A.topk + ((size_t)f * M + i) * kTopK);
 #pragma unroll
-                for (int t = 0; t < kTopK; t++) keys[t] = A.topk[((size_t)f * kTopK + t) * M + i];
+                for (int t = 0; t < kTopK / 4; t++) {
+                    const uint4 q = src[t];
+                    keys[4 * t] = q.x; keys[4 * t + 1] = q.y; keys[4 * t + 2] = q.z; keys[4 * t + 3] = q.w;
+                }
             }
         }
         int res = -1;  // rank of the accepted keypoint

@@ -11,11 +11,12 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 
 
 def per_kernel(sub, counter):
-    f = glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     acc = defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+            acc[name.split("(")[0]].append(float(r["Counter_Value"]))
     return acc
 
 
@@ -38,4 +39,8 @@ for kn in sorted(set(fetch) | set(write)):
     out["kernels"][kn] = {"launches": len(fetch.get(kn, [])), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                           "hbm_bytes_per_launch": fb + wb}
     print("%-70s n=%3d fetch=%8.1f MB write=%8.1f MB" % (kn[-70:], len(fetch.get(kn, [])), fb / 1e6, wb / 1e6))
+out["_meta"] = {"workload": "euroc_752x480", "frames_per_launch": 256,
+                "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+                "correction": "FETCH_SIZE x1024 x%.1f, WRITE_SIZE x1024 x%.1f (measured with tools/pmc_calib.bin, 4 B/lane and 16 B/lane streams)"
+                              % (calib[("FETCH_SIZE", "copy4")], calib[("WRITE_SIZE", "copy4")])}
 json.dump(out, open(os.path.join(root, "traffic.json"), "w"), indent=1)
