@@ -11,13 +11,14 @@
 
 namespace orbfe {
 
-// Output tile 256 x 8 per 256-thread block.  The source footprint (<= 20 rows x 528 px, i.e. scale
+// Output tile 128 x 16 per 256-thread block (pyramid levels are a few hundred pixels wide: wide tiles waste
+// a quarter of their lanes on the right edge).  The source footprint (<= 40 rows x 304 px, i.e. scale
 // factors up to ~2.2) is staged in LDS with dword loads whose addresses come from integer arithmetic
 // (no dependent table load in front of the staging); the weight tables are fetched meanwhile.
 // Every thread produces 2 x 4 pixels and stores two dwords.  xtab/ytab hold (x1 | Q11 weight << 16),
 // 16-byte aligned per level.  Algorithmic bytes per output pixel: 1 written + scale^2 read.
-constexpr int kRsTW = 256, kRsTH = 8;
-constexpr int kRsMaxRows = 20, kRsMaxCols = 528;
+constexpr int kRsTW = 128, kRsTH = 16;
+constexpr int kRsMaxRows = 40, kRsMaxCols = 304;
 
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, size_t srcFrameStride,
                                                      int sw, int sh, int spitch, int srcAligned4,
@@ -34,9 +35,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
     const int tid = threadIdx.x;
     const uint8_t* s = src + (size_t)f * srcFrameStride;
 
-    // this thread's outputs: 4 pixels at x0 in rows y and y + 4; table entries requested up front
-    const int x0 = tx0 + (tid & 63) * 4;
-    const int yA = ty0 + (tid >> 6), yB = yA + 4;
+    // this thread's outputs: 4 pixels at x0 in rows y and y + 8; table entries requested up front
+    const int x0 = tx0 + (tid & 31) * 4;
+    const int yA = ty0 + (tid >> 5), yB = yA + 8;
     const bool colOk = x0 < dw;
     uint4 xt4 = make_uint4(0, 0, 0, 0);
     uint32_t ytA = 0, ytB = 0;
@@ -44,13 +45,14 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
     if (yA < dh) ytA = ytab[yA];
     if (yB < dh) ytB = ytab[yB];
 
-    // source footprint of the tile from the same integer formula the tables were built with
+    // source footprint of the tile
     const int txLast = min(tx0 + kRsTW, dw) - 1;
     const int tyLast = min(ty0 + kRsTH, dh) - 1;
-    const int sx0 = (int)(((long long)tx0 * sw) / dw) & ~3;                      // dword-aligned left edge
-    const int sx1 = min((int)(((long long)txLast * sw) / dw) + 1, sw - 1);
-    const int sy0 = (int)(((long long)ty0 * sh) / dh);
-    const int sy1 = min((int)(((long long)tyLast * sh) / dh) + 1, sh - 1);
+    // (the low half of a table entry IS floor(x * sw / dw): four scalar loads instead of four 64-bit divisions)
+    const int sx0 = (int)(xtab[tx0] & 0xffffu) & ~3;                            // dword-aligned left edge
+    const int sx1 = min((int)(xtab[txLast] & 0xffffu) + 1, sw - 1);
+    const int sy0 = (int)(ytab[ty0] & 0xffffu);
+    const int sy1 = min((int)(ytab[tyLast] & 0xffffu) + 1, sh - 1);
     const int nrows = sy1 - sy0 + 1;
     const int ndw = (sx1 - sx0) / 4 + 1;                                          // dwords per staged row
     const bool staged = nrows <= kRsMaxRows && ndw * 4 <= kRsMaxCols;
@@ -92,18 +94,21 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
             const uint32_t wy = yt >> 16;
             const int y2 = min(y1 + 1, sh - 1);
             uint32_t outw = 0;
+            const uint32_t wyc = 2048u - wy;
+            // all four pixels are computed unconditionally (the x table is padded to a multiple of 4 with valid
+            // entries); every product has operands below 2^24, so the 24-bit multiplier (full rate) is exact:
+            // top, bot <= 255 * 2048 < 2^19, weights <= 2048
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                if (i < nvalid) {
-                    const int x1 = (int)(xt[i] & 0xffffu);
-                    const uint32_t wx = xt[i] >> 16;
-                    const int x2 = min(x1 + 1, sw - 1);
-                    const uint32_t a = fetch(y1, x1), b = fetch(y1, x2), c = fetch(y2, x1), e = fetch(y2, x2);
-                    const uint32_t top = a * (2048u - wx) + b * wx;
-                    const uint32_t bot = c * (2048u - wx) + e * wx;
-                    const uint32_t v = top * (2048u - wy) + bot * wy;
-                    outw |= ((v + (1u << 21)) >> 22) << (8 * i);
-                }
+                const int x1 = (int)(xt[i] & 0xffffu);
+                const uint32_t wx = xt[i] >> 16;
+                const uint32_t wxc = 2048u - wx;
+                const int x2 = min(x1 + 1, sw - 1);
+                const uint32_t a = fetch(y1, x1), b = fetch(y1, x2), c = fetch(y2, x1), e = fetch(y2, x2);
+                const uint32_t top = __umul24(a, wxc) + __umul24(b, wx);
+                const uint32_t bot = __umul24(c, wxc) + __umul24(e, wx);
+                const uint32_t v = __umul24(top, wyc) + __umul24(bot, wy) + (1u << 21);
+                outw |= (v >> 22) << (8 * i);
             }
             uint8_t* d = dst + (size_t)f * dstFrameStride + (size_t)y * dpitch;
             if (nvalid == 4) {

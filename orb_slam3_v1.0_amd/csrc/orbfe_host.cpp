@@ -122,6 +122,8 @@ void fill_resize_table(std::vector<uint32_t>& t, size_t off, int srcN, int dstN)
         const int wx = (int)(((int64_t)fx * 2048 + dstN / 2) / dstN);
         t[off + x] = (uint32_t)x1 | ((uint32_t)wx << 16);
     }
+    // the kernel evaluates whole groups of four: pad with the last entry (its results are never stored)
+    for (size_t x = (size_t)dstN; x < align_up((size_t)dstN, 4); x++) t[off + x] = t[off + dstN - 1];
 }
 
 void destroy_impl(orbfe_handle* h)
