@@ -25,11 +25,18 @@ __constant__ int8_t c_pattern[1024] = {
 };
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+// wave64 sum with DPP row operations (one VALU instruction per step instead of an LDS permute + add):
+// quad swaps, row half-mirror and mirror leave every lane of a 16-lane row with the row total; row_bcast 15 / 31
+// accumulate the rows into lane 63, which is read back as a scalar.
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* __restrict__ P,
@@ -39,11 +46,21 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
                                                            const uint32_t* __restrict__ lvlKp,
                                                            orbfe_keypoint* __restrict__ kpOut,
                                                            uint8_t* __restrict__ descOut, int* __restrict__ nOut,
-                                                           int* __restrict__ perLevelOut, int* __restrict__ statusOut)
+                                                           int* __restrict__ perLevelOut, int* __restrict__ statusOut,
+                                                           int frames, int slotBlocks)
 {
-    const int f = blockIdx.x;
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, so XCD x gets linear ids x, x+8, ...;
+    // give it the frames x, x+8, ... ONE AFTER THE OTHER (all keypoint blocks of a frame are consecutive on its
+    // XCD): the two level images a frame's patches gather from (about 2 MB) then stay in that XCD's 4 MB L2 while
+    // its ~1000 keypoints are processed, instead of 32 frames thrashing it.
+    const int xcd = blockIdx.x & 7;
+    const int q8 = blockIdx.x >> 3;
+    const int fgrp = q8 / slotBlocks;
+    const int sb = q8 - fgrp * slotBlocks;
+    const int f = fgrp * 8 + xcd;
+    if (f >= frames) return;
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);  // output index within the frame
+    const int slot = sb * 4 + (threadIdx.x >> 6);  // output index within the frame
     const int nL = P->nLevels;
     const uint32_t* cnt = counters + (size_t)f * nL * kCntWords;
 
@@ -61,7 +78,7 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
         total += c;
     }
     (void)base;
-    if (blockIdx.y == 0 && threadIdx.x == 0) {
+    if (sb == 0 && threadIdx.x == 0) {
         nOut[f] = total;
         if (perLevelOut)
             for (int q = 0; q < nL; q++) perLevelOut[(size_t)f * nL + q] = (int)cnt[q * kCntWords + kCntKp];
@@ -90,26 +107,41 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     const uint8_t* blur = ws + L.blurOff + (size_t)f * L.blurFrameStride;
     const int bpitch = L.pitch;
 
+    // Keypoints at least 19 px inside the level (the rotated BRIEF pattern reaches 18.4 px, the orientation patch
+    // 16) never touch the border: their sample addresses need no reflection.  One keypoint per wave, so the choice
+    // is wave-uniform.
+    const bool inner = x >= 19 && x < w - 19 && y >= 19 && y < h - 19;
+
     // ---- IC angle ----
     const int u = (lane & 31) - kHalfPatch;   // -15..16 (16 == idle lane 31/63)
     const int sgn = (lane < 32) ? 1 : -1;
-    // every level is >= 16 px and keypoints sit >= 6 px inside, so one reflection suffices
-    const int cx = reflect_near(x + u, w);
     int vals[kHalfPatch + 1];
+    if (inner) {
+        const uint8_t* pcol = img + (size_t)y * ipitch + (x + u);
+        const ptrdiff_t step = (ptrdiff_t)sgn * ipitch;
 #pragma unroll
-    for (int v = 0; v <= kHalfPatch; v++)  // 16 independent loads in flight
-        vals[v] = img[(size_t)reflect_near(y + sgn * v, h) * ipitch + cx];
-    int m10 = 0, m01 = 0;
+        for (int v = 0; v <= kHalfPatch; v++) vals[v] = pcol[v * step];  // 16 independent loads in flight
+    } else {
+        // every level is >= 16 px and keypoints sit >= 6 px inside, so one reflection suffices
+        const int cx = reflect_near(x + u, w);
+#pragma unroll
+        for (int v = 0; v <= kHalfPatch; v++)
+            vals[v] = img[(size_t)reflect_near(y + sgn * v, h) * ipitch + cx];
+    }
+    // the patch is a disc: column u is active in rows v <= c_umax[|u|] (the table is symmetric by construction,
+    // src/ORBextractor.cc:126-147); lane 31/63 (u == 16) is idle, and row 0 belongs to the upper half only
     const int au = abs(u);
+    const int vmax = au <= kHalfPatch ? c_umax[au] : -1;
+    const int vmin = sgn < 0 ? 1 : 0;
+    int sumv = 0, m01 = 0;
 #pragma unroll
     for (int v = 0; v <= kHalfPatch; v++) {
-        const bool act = (au <= c_umax[v]) && !(v == 0 && sgn < 0);  // c_umax <= 15 masks the idle lane (u == 16)
-        const int val = act ? vals[v] : 0;
-        m10 += u * val;
-        m01 += sgn * v * val;
+        const int val = (v <= vmax && v >= vmin) ? vals[v] : 0;
+        sumv += val;
+        m01 += v * val;
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
+    const int m10 = wave_sum(u * sumv);
+    m01 = wave_sum(sgn * m01);
     const float angle = atan2_deg((float)m01, (float)m10);
 
     // ---- steered BRIEF ----
@@ -125,10 +157,14 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
         float c0 = x0 * a; const float c0b = y0 * b; c0 = c0 - c0b;
         float r1 = x1 * b; const float r1b = y1 * a; r1 = r1 + r1b;
         float c1 = x1 * a; const float c1b = y1 * b; c1 = c1 - c1b;
-        const int ya = reflect_near(y + __float2int_rn(r0), h), xa = reflect_near(x + __float2int_rn(c0), w);
-        const int yb = reflect_near(y + __float2int_rn(r1), h), xb = reflect_near(x + __float2int_rn(c1), w);
-        t0[q] = blur[(size_t)ya * bpitch + xa];
-        t1[q] = blur[(size_t)yb * bpitch + xb];
+        int ya = y + __float2int_rn(r0), xa = x + __float2int_rn(c0);
+        int yb = y + __float2int_rn(r1), xb = x + __float2int_rn(c1);
+        if (!inner) {
+            ya = reflect_near(ya, h); xa = reflect_near(xa, w);
+            yb = reflect_near(yb, h); xb = reflect_near(xb, w);
+        }
+        t0[q] = blur[ya * bpitch + xa];  // level pixels < 2^24: 32-bit offsets
+        t1[q] = blur[yb * bpitch + xb];
     }
     unsigned long long bits[4];
 #pragma unroll
@@ -161,9 +197,10 @@ void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const Pipeli
                          int* perLevelOut, int* statusOut)
 {
     dim3 block(256);
-    dim3 grid(frames, (kpCapFrame + 3) / 4);
+    const int slotBlocks = (kpCapFrame + 3) / 4;
+    dim3 grid((unsigned)(((frames + 7) / 8) * 8 * slotBlocks));
     hipLaunchKernelGGL(orient_brief_kernel, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch, ws,
-                       counters, lvlKp, kpOut, descOut, nOut, perLevelOut, statusOut);
+                       counters, lvlKp, kpOut, descOut, nOut, perLevelOut, statusOut, frames, slotBlocks);
 }
 
 }  // namespace orbfe
