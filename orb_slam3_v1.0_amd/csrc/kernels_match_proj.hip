@@ -11,9 +11,9 @@
 //    cell y, keypoint index).  The keypoints of a frame are SORTED by that visit position once per call
 //    (their position in the sorted order is the "rank"), so a candidate key is one 32-bit word
 //    distance << 20 | rank.  The keypoints are STORED level-major, in visit order inside a level, with one
-//    cell-range table per level: the cells iy = minCY..maxCY of grid column ix at level l are one
-//    contiguous range, and a map point predicted at level L only walks levels L-1 and L (src/Frame.cc:437-452)
-//    -- <= 2 * (maxCX-minCX+1) short ranges instead of the whole frame.
+//    column-start table per level: the grid columns minCX..maxCX of level l are one contiguous slot range, and a
+//    map point predicted at level L only walks levels L-1 and L (src/Frame.cc:437-452) -- two ranges and four
+//    table loads per map point; the cell-row test runs on the record of every visited keypoint.
 //  * The function is greedy: a keypoint already holding a map point with observations is skipped
 //    (:77-79), including points written earlier in the SAME loop.  Let claim[rank] = smallest index
 //    of an accepted map point (with observations) whose best match is that keypoint.  Evaluating every
@@ -28,7 +28,7 @@
 //    rescanned exactly (one wave over the rank range of its window columns, LDS-resident frame).
 //
 // Pipeline per call (B frames), all asynchronous on one stream, no host round trip:
-//   grid (cell per keypoint, sort by visit position, cell-range table) -> map points ordered by
+//   grid (cell per keypoint, sort by visit position, column-start tables) -> map points ordered by
 //   (level, tile) -> top-K candidate keys per map point (thread per map point) -> ONE persistent block
 //   per frame resolves the claims (claim table in LDS) and writes the final matches.
 #include <algorithm>
@@ -53,7 +53,6 @@ constexpr int kRankBits = 20;
 constexpr uint32_t kRankMask = (1u << kRankBits) - 1u;
 constexpr int kSortLds = 2048;    // frames up to this many keypoints are sorted in LDS
 constexpr int kMaxCells = 1 << 22;          // grid cells (cols * rows)
-constexpr long long kMaxTableEntries = 1ll << 24;  // cells x levels: the cell-range tables take 4 B per entry per frame
 
 struct GridDesc {
     int cols, rows;
@@ -82,7 +81,7 @@ struct ProjArgs {
     int* rankOf;                  // [B][kpStride] keypoint index -> rank (global sort path only)
     int4* rec;                    // [B][kpStride] per storage slot: {rank, octave | cell y << 8, x bits, y bits}
     unsigned long long* descS;    // [B][kpStride][4] descriptors in storage order
-    int* colStart;                // [B][tabLevels][cols*rows + 1]: first storage slot of (level, cell v = cx*rows + cy)
+    int* colStart;                // [B][tabLevels][cols + 1]: first storage slot of (level, grid column cx)
     int tabLevels;                // min(nLevels, 32)
     int* cnt;                     // [B][M] number of candidates (dist < 256) per map point
     uint32_t* topk;               // [B][M][kTopK] sorted smallest keys (one 64-byte line per map point)
@@ -250,12 +249,14 @@ __global__ __launch_bounds__(1024) void proj_grid_kernel(ProjArgs A)
         dd[2] = desc[(size_t)idx * 4 + 2];
         dd[3] = desc[(size_t)idx * 4 + 3];
     }
-    // colStart[l][v] = first storage slot whose (level, cell) is >= (l, v) (lower bound), v = 0..nCells
-    int* cs = A.colStart + (size_t)f * A.tabLevels * (nCells + 1);
-    const int nTab = A.tabLevels * (nCells + 1);
+    // colStart[l][cx] = first storage slot whose (level, cell) is >= (l, cx * rows) (lower bound), cx = 0..cols:
+    // the keypoints of grid columns [a, b] of level l are the slots [colStart[l][a], colStart[l][b + 1])
+    const int tabStride = A.g.cols + 1;
+    int* cs = A.colStart + (size_t)f * A.tabLevels * tabStride;
+    const int nTab = A.tabLevels * tabStride;
     for (int e = tid; e < nTab; e += 1024) {
-        const int l = e / (nCells + 1);
-        const int v = e - l * (nCells + 1);
+        const int l = e / tabStride;
+        const int v = (e - l * tabStride) * A.g.rows;
         const unsigned long long want = ((unsigned long long)l << (kCellBits + 1)) | (unsigned long long)v;
         int lo = 0, hi = n;
         while (lo < hi) {
@@ -332,35 +333,46 @@ __device__ __forceinline__ int topk_scan(const ProjArgs& A, const MpWindow& w, c
                                          unsigned long long d3, uint32_t (&keys)[kTopK])
 {
     int total = 0;
-    const int rows = A.g.rows;
-    for (int l = max(w.minLevel, 0); l <= w.maxLevel; l++) {  // levels that pass src/Frame.cc:437-452
-        const int* csl = cs + (size_t)l * tabStride;
-        for (int cx = w.minCX; cx <= w.maxCX; cx++) {
-            const int s = csl[cx * rows + w.minCY], e = csl[cx * rows + w.maxCY + 1];
-            for (int p = s; p < e; p++) {
-                int4 q;
-                if constexpr (LDS) q = S->rec[p - segBase];
-                else q = rec[p];
-                const float dx = __int_as_float(q.z) - w.x, dy = __int_as_float(q.w) - w.y;
-                if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;  // src/Frame.cc:461
-                int dist;
-                if constexpr (LDS) {
-                    const unsigned long long* kd = S->desc[p - segBase];
-                    dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
-                } else {
-                    const unsigned long long* kd = descS + (size_t)p * 4;
-                    dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
-                }
-                if (dist >= A.dCut) continue;  // cannot change the verdict (proj_dcut)
-                total++;
-                uint32_t key = make_key32(dist, q.x);
-                if (key < keys[kTopK - 1]) {  // sorted insert
+    // One contiguous slot range per level: all rows of the window's grid columns (columns are contiguous in the
+    // level-major visit order); the cell-row test runs per keypoint on the record.  Compared with one range per
+    // (level, column) this visits about 1.6x more records, but needs 4 table loads per map point instead of ~60
+    // dependent ones, and the trip counts of the 64 lanes of a wave are far more uniform.
+    const int l0 = max(w.minLevel, 0), l1 = w.maxLevel;
+    int plo[2], phi[2];
 #pragma unroll
-                    for (int t = 0; t < kTopK; t++) {
-                        const uint32_t lo = min(key, keys[t]);
-                        key = max(key, keys[t]);
-                        keys[t] = lo;
-                    }
+    for (int k = 0; k < 2; k++) {
+        const int l = min(l0 + k, l1);
+        const int* csl = cs + (size_t)l * tabStride;
+        plo[k] = csl[w.minCX];
+        phi[k] = (l0 + k <= l1) ? csl[w.maxCX + 1] : plo[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {  // levels that pass src/Frame.cc:437-452 (at most two)
+        for (int p = plo[k]; p < phi[k]; p++) {
+            int4 q;
+            if constexpr (LDS) q = S->rec[p - segBase];
+            else q = rec[p];
+            const int cy = q.y >> 8;
+            if (cy < w.minCY || cy > w.maxCY) continue;
+            const float dx = __int_as_float(q.z) - w.x, dy = __int_as_float(q.w) - w.y;
+            if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;  // src/Frame.cc:461
+            int dist;
+            if constexpr (LDS) {
+                const unsigned long long* kd = S->desc[p - segBase];
+                dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
+            } else {
+                const unsigned long long* kd = descS + (size_t)p * 4;
+                dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
+            }
+            if (dist >= A.dCut) continue;  // cannot change the verdict (proj_dcut)
+            total++;
+            uint32_t key = make_key32(dist, q.x);
+            if (key < keys[kTopK - 1]) {  // sorted insert
+#pragma unroll
+                for (int t = 0; t < kTopK; t++) {
+                    const uint32_t lo = min(key, keys[t]);
+                    key = max(key, keys[t]);
+                    keys[t] = lo;
                 }
             }
         }
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
         atomicMax(&sLvlHi, w.maxLevel);
     }
     __syncthreads();
-    const int tabStride = A.g.cols * A.g.rows + 1;
+    const int tabStride = A.g.cols + 1;
     const int* cs = A.colStart + (size_t)f * A.tabLevels * tabStride;
     const int4* rec = A.rec + (size_t)f * A.kpStride;
     const unsigned long long* descS = A.descS + (size_t)f * A.kpStride * 4;
@@ -456,8 +468,7 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
     k1 = kKey32None;
     k2 = kKey32None;
     if (w.valid) {  // wave-uniform
-        const int rows = A.g.rows;
-        const int tabStride = A.g.cols * rows + 1;
+        const int tabStride = A.g.cols + 1;
         const int* cs = A.colStart + (size_t)f * A.tabLevels * tabStride;
         const int4* rec = A.rec + (size_t)f * A.kpStride;
         const unsigned long long* descS = A.descS + (size_t)f * A.kpStride * 4;
@@ -466,7 +477,7 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
         d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
         for (int l = max(w.minLevel, 0); l <= w.maxLevel; l++) {
             const int* csl = cs + (size_t)l * tabStride;
-            const int plo = csl[w.minCX * rows], phi = csl[(w.maxCX + 1) * rows];  // all rows of the window's columns
+            const int plo = csl[w.minCX], phi = csl[w.maxCX + 1];  // all rows of the window's columns
             for (int p = plo + lane; p < phi; p += 64) {
                 int4 q;
                 if constexpr (LDS) q = S->rec[p];
@@ -686,16 +697,17 @@ __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frus
         if (!w.valid) break;
         const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(mpDesc + (size_t)i * 32);
         const unsigned long long d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
-        const int rows = A.g.rows;
-        const int tabStride = A.g.cols * rows + 1;
+        const int tabStride = A.g.cols + 1;
         uint32_t best = kKey32None;
         for (int l = max(lvl - 1, 0); l <= min(lvl, A.tabLevels - 1); l++) {  // :787
             const int* csl = A.colStart + (size_t)l * tabStride;
             const float invS2 = invLevelSigma2[l];
-            for (int cx = w.minCX; cx <= w.maxCX; cx++) {
-                const int s = csl[cx * rows + w.minCY], e = csl[cx * rows + w.maxCY + 1];
+            {
+                const int s = csl[w.minCX], e = csl[w.maxCX + 1];  // all rows of the window's columns
                 for (int sl = s; sl < e; sl++) {
                     const int4 rq = A.rec[sl];
+                    const int cy = rq.y >> 8;
+                    if (cy < w.minCY || cy > w.maxCY) continue;
                     const float kx = __int_as_float(rq.z), ky = __int_as_float(rq.w);
                     if (!(fabsf(kx - u) < w.r && fabsf(ky - v) < w.r)) continue;  // src/KeyFrame.cc:826
                     const float ex = u - kx, ey = v - ky;
@@ -745,7 +757,6 @@ int proj_dcut(float nnRatio)
 int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::string& err)
 {
     const int B = A.B, M = A.M;
-    const size_t nCells = (size_t)A.g.cols * A.g.rows;
     A.sortCap = 1;
     while (A.sortCap < A.kpStride) A.sortCap <<= 1;
     const bool ldsSort = A.kpStride <= kSortLds;
@@ -757,7 +768,7 @@ int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::st
     const size_t oRankOf = sc.take(ldsSort ? 8 : (size_t)B * A.kpStride * sizeof(int));
     const size_t oRec = sc.take((size_t)B * A.kpStride * sizeof(int4));
     const size_t oDescS = sc.take((size_t)B * A.kpStride * 32);
-    const size_t oCol = sc.take((size_t)B * A.tabLevels * (nCells + 1) * sizeof(int));
+    const size_t oCol = sc.take((size_t)B * A.tabLevels * ((size_t)A.g.cols + 1) * sizeof(int));
     const size_t oCnt = sc.take((size_t)B * std::max(M, 1) * sizeof(int));
     const size_t oTopk = sc.take((size_t)B * kTopK * std::max(M, 1) * sizeof(uint32_t));
     const size_t oClaim = sc.take((size_t)B * A.kpStride * sizeof(int));
@@ -820,8 +831,7 @@ int match_projection_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view*
     *nMatches = 0;
     if (n == 0 || M == 0) return ORBFE_OK;
     if (n >= (1 << 20) || F->grid_cols > 65535 || F->grid_rows > 32767 || F->n_levels < 1 ||
-        (long long)F->grid_cols * F->grid_rows > kMaxCells ||
-        (long long)F->grid_cols * F->grid_rows * std::min(F->n_levels, 32) > kMaxTableEntries)
+        (long long)F->grid_cols * F->grid_rows > kMaxCells)
         return ORBFE_ERR_UNSUPPORTED;
     for (int i = 0; i < M; i++)
         if (mps[i].in_view && (mps[i].level < 0 || mps[i].level >= F->n_levels)) return ORBFE_ERR_INVALID_ARG;
@@ -890,8 +900,7 @@ int match_projection_batch_device(MatchScratch& m, hipStream_t s, int B, const o
                                   int farPoints, float thFar, float nnRatio, int* dMatchOut, int* dNMatches,
                                   std::string& err)
 {
-    if (kpStride >= (1 << 20) || gridCols > 65535 || gridRows > 32767 || (long long)gridCols * gridRows > kMaxCells ||
-        (long long)gridCols * gridRows * std::min(std::max(nLevels, 1), 32) > kMaxTableEntries)
+    if (kpStride >= (1 << 20) || gridCols > 65535 || gridRows > 32767 || (long long)gridCols * gridRows > kMaxCells)
         return ORBFE_ERR_UNSUPPORTED;
     ProjArgs A{};
     A.B = B; A.M = M; A.kpStride = kpStride;
@@ -917,8 +926,7 @@ int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, 
     const int n = KF->n;
     if (n == 0 || M == 0) return ORBFE_OK;
     if (n >= (1 << 20) || KF->grid_cols > 65535 || KF->grid_rows > 32767 || KF->n_levels < 1 ||
-        (long long)KF->grid_cols * KF->grid_rows > kMaxCells ||
-        (long long)KF->grid_cols * KF->grid_rows * std::min(KF->n_levels, 32) > kMaxTableEntries)
+        (long long)KF->grid_cols * KF->grid_rows > kMaxCells)
         return ORBFE_ERR_UNSUPPORTED;
     if (F->n_levels > KF->n_levels) return ORBFE_ERR_INVALID_ARG;  // predicted levels index the key frame's scale tables
     Carver in;
