@@ -443,7 +443,6 @@ struct ResolveLds {
     int claim[kResN];                     // by rank
     uint8_t oct[kResN];                   // by rank
     int4 rec[kResN];                      // by storage slot: {rank, octave | cell y << 8, x bits, y bits}
-    unsigned long long desc[kResN][4];    // by storage slot
 };
 
 __device__ __forceinline__ void wave_top2_u32(uint32_t& k1, uint32_t& k2)
@@ -488,11 +487,8 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
                 const float dx = __int_as_float(q.z) - w.x, dy = __int_as_float(q.w) - w.y;
                 if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;
                 int dist;
-                if constexpr (LDS)
-                    dist = __popcll(S->desc[p][0] ^ d4[0]) + __popcll(S->desc[p][1] ^ d4[1]) +
-                           __popcll(S->desc[p][2] ^ d4[2]) + __popcll(S->desc[p][3] ^ d4[3]);
-                else
-                    dist = hamming256(reinterpret_cast<const uint2*>(descS + (size_t)p * 4), d4);
+                // descriptors of the few survivors come from L2: keeping them in LDS would take 64 KB per block
+                dist = hamming256(reinterpret_cast<const uint2*>(descS + (size_t)p * 4), d4);
                 if (dist >= A.dCut) continue;
                 const uint32_t key = make_key32(dist, q.x);
                 if (key < k1) { k2 = k1; k1 = key; }
@@ -527,12 +523,10 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
     for (int r = tid; r < n; r += kResolveThreads) claim[r] = (initObs && initObs[order[r]] > 0) ? -1 : kClaimFree;
     const uint8_t* octByRank = A.octByRank + (size_t)f * A.kpStride;
     if constexpr (LDS) {
-        const unsigned long long* descS = A.descS + (size_t)f * A.kpStride * 4;
         for (int r = tid; r < n; r += kResolveThreads) {
             S.rec[r] = rec[r];
             S.oct[r] = octByRank[r];
         }
-        for (int j = tid; j < n * 4; j += kResolveThreads) S.desc[0][j] = descS[j];
     }
     if (tid == 0) sCount = 0;
     int nAccepted = 0;
