@@ -225,6 +225,7 @@ int orbfe_match_initialization(orbfe_handle *h, const orbfe_frame_view *f1, cons
  * Map-point projection: Frame::isInFrustum for a batch
  * ---------------------------------------------------------------------------------------- */
 #define ORBFE_CAMERA_PINHOLE 0
+#define ORBFE_CAMERA_KANNALA_BRANDT8 1
 
 /* what Frame::isInFrustum reads from the frame (src/Frame.cc:272-331) */
 typedef struct orbfe_frustum {
@@ -232,11 +233,12 @@ typedef struct orbfe_frustum {
     float tcw[3];             /* GetTcw() */
     float twc[3];             /* GetTwc() (camera centre) */
     float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
-    float fx, fy, cx, cy;     /* Pinhole mvParameters[0..3] (src/CameraModels/Pinhole.cpp:41-47) */
+    float fx, fy, cx, cy;     /* mvParameters[0..3] (src/CameraModels/Pinhole.cpp:41-47, KannalaBrandt8.cpp:66-83) */
+    float k1, k2, k3, k4;     /* KannalaBrandt8 mvParameters[4..7]; ignored by the pinhole model */
     float mbf;                /* stereo baseline * fx (mTrackProjXR) */
     float log_scale_factor;   /* mfLogScaleFactor (src/Frame.cc:75) */
     int n_levels;             /* mnScaleLevels */
-    int camera_model;         /* ORBFE_CAMERA_PINHOLE */
+    int camera_model;         /* ORBFE_CAMERA_PINHOLE or ORBFE_CAMERA_KANNALA_BRANDT8 */
 } orbfe_frustum;
 
 /* what it reads from a MapPoint, plus the two skip conditions of Tracking::SearchLocalPoints

@@ -397,6 +397,33 @@ void orc_vocab_transform(int nNodes, const int *childOff, const int *childIdx, c
  * contraction (the reference's Eigen expressions compile to whatever -march=native allows), norms are
  * sqrtf((x*x + y*y) + z*z), and log() is orc_spec_logf below (the reference calls the platform libm).
  * ------------------------------------------------------------------------------------------ */
+/* GeometricCamera::project of the two camera models (src/CameraModels/Pinhole.cpp:41-47,
+ * src/CameraModels/KannalaBrandt8.cpp:66-83).  KannalaBrandt8 uses the S5 polynomial atan2 / cos / sin (the
+ * reference calls libm): psi in radians is turned into degrees in [0, 360) for orc_cos_sin_deg. */
+static void camera_project(const orc_frustum *F, float x, float y, float z, float *u, float *v)
+{
+    if (F->cameraModel == 0) {
+        *u = F->fx * x / z + F->cx;
+        *v = F->fy * y / z + F->cy;
+        return;
+    }
+    const float x2_plus_y2 = x * x + y * y;
+    const float theta = orc_spec_atan2f(sqrtf(x2_plus_y2), z);
+    const float psi = orc_spec_atan2f(y, x);
+    const float theta2 = theta * theta;
+    const float theta3 = theta * theta2;
+    const float theta5 = theta3 * theta2;
+    const float theta7 = theta5 * theta2;
+    const float theta9 = theta7 * theta2;
+    const float r = (((theta + F->k1 * theta3) + F->k2 * theta5) + F->k3 * theta7) + F->k4 * theta9;
+    float deg = psi * 0x1.ca5dc2p+5f; /* 180 / pi */
+    if (deg < 0.0f) deg = deg + 360.0f;
+    float c, s;
+    orc_cos_sin_deg(deg, &c, &s);
+    *u = F->fx * r * c + F->cx;
+    *v = F->fy * r * s + F->cy;
+}
+
 float orc_spec_logf(float x)
 {
     /* x = m * 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716:
@@ -444,8 +471,8 @@ void orc_is_in_frustum(const orc_frustum *F, int n, const orc_world_point *pts, 
         const float pcDist = sqrtf((pcx * pcx + pcy * pcy) + pcz * pcz);
         const float invz = 1.0f / pcz;
         if (pcz < 0.0f) continue; /* :288 */
-        const float u = F->fx * pcx / pcz + F->cx; /* Pinhole.cpp:43-44 */
-        const float v = F->fy * pcy / pcz + F->cy;
+        float u, v;
+        camera_project(F, pcx, pcy, pcz, &u, &v); /* mpCamera->project(Pc), :291 */
         if (u < F->minX || u > F->maxX) continue; /* NaN (pcz == 0 with pcx == 0) passes, as in the reference */
         if (v < F->minY || v > F->maxY) continue;
         o->projX = u; /* :299-300: set before the distance test */
@@ -499,8 +526,8 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
         const float pcz = ((F->rcw[6] * X + F->rcw[7] * Y) + F->rcw[8] * Z) + F->tcw[2];
         if (pcz < 0.0f) continue; /* :725 */
         const float invz = 1 / pcz;
-        const float u = F->fx * pcx / pcz + F->cx;
-        const float v = F->fy * pcy / pcz + F->cy;
+        float u, v;
+        camera_project(F, pcx, pcy, pcz, &u, &v);
         if (!(u >= F->minX && u < F->maxX && v >= F->minY && v < F->maxY)) continue; /* KeyFrame::IsInImage */
         const float ur = u - F->mbf * invz;
         const float maxD = 1.1f * p->maxDistance, minD = 0.9f * p->minDistance;

@@ -90,7 +90,7 @@ static inline int px_reflect(const uint8_t *img, int w, int h, int pitch, int y,
 #define F_DEG2RAD 0x1.1df46ap-6f   /* (float)(CV_PI/180.f), src/cuda/Orb_gpu.cu:327 */
 
 /* radians, emulates atan2f(y, x) to ~2 ulp with a fixed op sequence */
-static float spec_atan2f(float y, float x)
+float orc_spec_atan2f(float y, float x)
 {
     float ax = fabsf(x), ay = fabsf(y);
     float mx = ax > ay ? ax : ay;
@@ -122,7 +122,7 @@ static float spec_atan2f(float y, float x)
 /* src/cuda/Angle_gpu.cu:73-75 : atan2f -> +2pi if negative -> degrees */
 float orc_atan2_deg(float m01, float m10)
 {
-    float kp_dir = spec_atan2f(m01, m10);
+    float kp_dir = orc_spec_atan2f(m01, m10);
     if (kp_dir < 0.0f) kp_dir = kp_dir + 2.0f * F_PI;
     kp_dir = kp_dir * (180.0f / F_PI);
     return kp_dir;

@@ -76,6 +76,7 @@ int orc_distribute(int n, const int16_t *xy, const int *resp, int W, int H, int 
 float orc_ic_angle(const uint8_t *img, int w, int h, int pitch, int x, int y);
 void orc_brief(const uint8_t *img, int w, int h, int pitch, int x, int y, float angleDeg,
                uint8_t desc[32]);
+float orc_spec_atan2f(float y, float x); /* radians, S5 */
 float orc_atan2_deg(float m01, float m10);
 void orc_cos_sin_deg(float angleDeg, float *c, float *s);
 
@@ -136,6 +137,7 @@ typedef struct {
     float rcw[9], tcw[3], twc[3];
     float minX, maxX, minY, maxY;
     float fx, fy, cx, cy;
+    float k1, k2, k3, k4; /* KannalaBrandt8 */
     float mbf, logScaleFactor;
     int nLevels, cameraModel;
 } orc_frustum;

@@ -126,4 +126,32 @@ __device__ __forceinline__ float spec_logf(float x)
     return ef * 0x1.62ep-1f + (r + ef * 0x1.0bfbe8p-15f);
 }
 
+// GeometricCamera::project of the two camera models (src/CameraModels/Pinhole.cpp:41-47,
+// src/CameraModels/KannalaBrandt8.cpp:66-83), same operation sequence as oracle/match_oracle.c camera_project.
+// `Frustum` is orbfe_frustum (include/orbfe.h); a template keeps this header free of the C ABI include.
+template <class Frustum>
+__device__ __forceinline__ void camera_project(const Frustum& F, float x, float y, float z, float& u, float& v)
+{
+    if (F.camera_model == 0) {
+        u = F.fx * x / z + F.cx;
+        v = F.fy * y / z + F.cy;
+        return;
+    }
+    const float x2_plus_y2 = x * x + y * y;
+    const float theta = spec_atan2f(sqrtf(x2_plus_y2), z);
+    const float psi = spec_atan2f(y, x);
+    const float theta2 = theta * theta;
+    const float theta3 = theta * theta2;
+    const float theta5 = theta3 * theta2;
+    const float theta7 = theta5 * theta2;
+    const float theta9 = theta7 * theta2;
+    const float r = (((theta + F.k1 * theta3) + F.k2 * theta5) + F.k3 * theta7) + F.k4 * theta9;
+    float deg = psi * 0x1.ca5dc2p+5f;  // 180 / pi
+    if (deg < 0.0f) deg = deg + 360.0f;
+    float c, s;
+    cos_sin_deg(deg, c, s);
+    u = F.fx * r * c + F.cx;
+    v = F.fy * r * s + F.cy;
+}
+
 }  // namespace orbfe

@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void frustum_kernel(orbfe_frustum F, int n, co
         const float pcDist = sqrtf((pcx * pcx + pcy * pcy) + pcz * pcz);
         const float invz = __fdiv_rn(1.0f, pcz);
         if (pcz < 0.0f) break;  // :288
-        const float u = __fdiv_rn(F.fx * pcx, pcz) + F.cx;  // Pinhole.cpp:43-44
-        const float v = __fdiv_rn(F.fy * pcy, pcz) + F.cy;
+        float u, v;
+        camera_project(F, pcx, pcy, pcz, u, v);  // mpCamera->project(Pc), :291
         if (u < F.min_x || u > F.max_x) break;
         if (v < F.min_y || v > F.max_y) break;
         o.proj_x = u;  // :299-300: set before the distance test
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void frustum_kernel(orbfe_frustum F, int n, co
 int frustum_validate(const orbfe_frustum* F)
 {
     if (!F) return ORBFE_ERR_INVALID_ARG;
-    if (F->camera_model != ORBFE_CAMERA_PINHOLE) return ORBFE_ERR_UNSUPPORTED;  // KannalaBrandt8: not built yet
+    if (F->camera_model != ORBFE_CAMERA_PINHOLE && F->camera_model != ORBFE_CAMERA_KANNALA_BRANDT8) return ORBFE_ERR_UNSUPPORTED;
     if (F->n_levels < 1 || !(F->log_scale_factor > 0.0f)) return ORBFE_ERR_INVALID_ARG;
     return ORBFE_OK;
 }

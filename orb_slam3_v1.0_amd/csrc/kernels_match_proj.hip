@@ -665,8 +665,8 @@ __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frus
         const float pcz = ((F.rcw[6] * X + F.rcw[7] * Y) + F.rcw[8] * Z) + F.tcw[2];
         if (pcz < 0.0f) break;  // :725
         const float invz = 1.0f / pcz;
-        const float u = F.fx * pcx / pcz + F.cx;
-        const float v = F.fy * pcy / pcz + F.cy;
+        float u, v;
+        camera_project(F, pcx, pcy, pcz, u, v);
         if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) break;  // KeyFrame::IsInImage
         const float ur = u - F.mbf * invz;
         const float maxD = 1.1f * p.max_distance, minD = 0.9f * p.min_distance;

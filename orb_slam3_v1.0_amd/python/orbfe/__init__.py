@@ -44,7 +44,8 @@ class Frustum(C.Structure):
     """orbfe_frustum: what Frame::isInFrustum reads from the frame (src/Frame.cc:272-331)."""
     _fields_ = [("rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("twc", C.c_float * 3), ("min_x", C.c_float),
                 ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("fx", C.c_float), ("fy", C.c_float),
-                ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float), ("log_scale_factor", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float),
+                ("k4", C.c_float), ("mbf", C.c_float), ("log_scale_factor", C.c_float),
                 ("n_levels", C.c_int), ("camera_model", C.c_int)]
 
 

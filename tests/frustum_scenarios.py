@@ -13,7 +13,7 @@ def rot(rx, ry, rz):
     return (Rz @ Ry @ Rx).astype(np.float32)
 
 
-def fill_frustum(F, names, W=752.0, H=480.0, n_levels=8, scale=1.2, seed=0):
+def fill_frustum(F, names, W=752.0, H=480.0, n_levels=8, scale=1.2, seed=0, kb8=False):
     """`names` maps the logical field names to the struct's (oracle: camelCase, product: snake_case)."""
     rng = np.random.default_rng(seed)
     R = rot(*(rng.uniform(-0.2, 0.2, 3)))
@@ -21,7 +21,8 @@ def fill_frustum(F, names, W=752.0, H=480.0, n_levels=8, scale=1.2, seed=0):
     twc = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32)
     vals = dict(rcw=R.reshape(-1), tcw=t, twc=twc, min_x=0.0, max_x=W, min_y=0.0, max_y=H, fx=458.654, fy=457.296,
                 cx=367.215, cy=248.375, mbf=47.9, log_scale_factor=float(np.log(np.float32(scale))), n_levels=n_levels,
-                camera_model=0)
+                camera_model=1 if kb8 else 0, k1=-0.0135 if kb8 else 0.0, k2=0.021 if kb8 else 0.0,
+                k3=-0.0107 if kb8 else 0.0, k4=0.0023 if kb8 else 0.0)
     for k, v in vals.items():
         f = names[k]
         if k in ("rcw", "tcw", "twc"):

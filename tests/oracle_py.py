@@ -23,7 +23,8 @@ WP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("minDistance", "
 class Frustum(C.Structure):
     _fields_ = [("rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("twc", C.c_float * 3), ("minX", C.c_float),
                 ("maxX", C.c_float), ("minY", C.c_float), ("maxY", C.c_float), ("fx", C.c_float), ("fy", C.c_float),
-                ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float), ("logScaleFactor", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float),
+                ("k4", C.c_float), ("mbf", C.c_float), ("logScaleFactor", C.c_float),
                 ("nLevels", C.c_int), ("cameraModel", C.c_int)]
 
 
@@ -81,6 +82,8 @@ def lib():
         L.orc_search_for_initialization.argtypes = [vp, vp, ci, cf, ci, vp]
         L.orc_vocab_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, vp]
         L.orc_vocab_transform.restype = None
+        L.orc_spec_atan2f.argtypes = [cf, cf]
+        L.orc_spec_atan2f.restype = cf
         L.orc_spec_logf.argtypes = [cf]
         L.orc_spec_logf.restype = cf
         L.orc_is_in_frustum.argtypes = [C.POINTER(Frustum), ci, vp, vp, vp]
@@ -321,3 +324,7 @@ def search_for_triangulation(off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1
                                            _p(F), float(np.float32(ep[0])), float(np.float32(ep[1])), int(bOnlyStereo),
                                            int(bCoarse), int(checkOrientation), _p(out))
     return n, out[:len(kp1)].copy()
+
+
+def spec_atan2f(y, x):
+    return float(lib().orc_spec_atan2f(float(np.float32(y)), float(np.float32(x))))

@@ -9,7 +9,8 @@ import frustum_scenarios as FS
 import oracle_py as O
 
 ON = dict(rcw="rcw", tcw="tcw", twc="twc", min_x="minX", max_x="maxX", min_y="minY", max_y="maxY", fx="fx", fy="fy", cx="cx",
-          cy="cy", mbf="mbf", log_scale_factor="logScaleFactor", n_levels="nLevels", camera_model="cameraModel")
+          cy="cy", k1="k1", k2="k2", k3="k3", k4="k4", mbf="mbf", log_scale_factor="logScaleFactor", n_levels="nLevels",
+          camera_model="cameraModel")
 OP = dict(x="x", y="y", z="z", min_distance="minDistance", max_distance="maxDistance", bad="bad", observations="observations",
           skip="skip")
 PN = {k: k for k in ON}
@@ -54,8 +55,24 @@ def py_in_frustum(v, p):
         return o, xr
     with np.errstate(divide="ignore", invalid="ignore"):
         invz = f32(f32(1) / pc[2])
-        u = f32(f32(f32(f32(v["fx"]) * pc[0]) / pc[2]) + f32(v["cx"]))
-        w = f32(f32(f32(f32(v["fy"]) * pc[1]) / pc[2]) + f32(v["cy"]))
+        if v["camera_model"] == 0:
+            u = f32(f32(f32(f32(v["fx"]) * pc[0]) / pc[2]) + f32(v["cx"]))
+            w = f32(f32(f32(f32(v["fy"]) * pc[1]) / pc[2]) + f32(v["cy"]))
+        else:  # KannalaBrandt8.cpp:66-83 on the S5 primitives (pinned by tests/test_oracle_kat.py)
+            th = f32(O.spec_atan2f(np.sqrt(f32(f32(pc[0] * pc[0]) + f32(pc[1] * pc[1]))), pc[2]))
+            psi = f32(O.spec_atan2f(pc[1], pc[0]))
+            t2 = f32(th * th)
+            t3 = f32(th * t2)
+            t5 = f32(t3 * t2)
+            t7 = f32(t5 * t2)
+            t9 = f32(t7 * t2)
+            r = f32(f32(f32(f32(th + f32(f32(v["k1"]) * t3)) + f32(f32(v["k2"]) * t5)) + f32(f32(v["k3"]) * t7)) + f32(f32(v["k4"]) * t9))
+            deg = f32(psi * f32(float.fromhex("0x1.ca5dc2p+5")))
+            if deg < 0:
+                deg = f32(deg + f32(360))
+            cs_, s_ = O.cos_sin_deg(deg)
+            u = f32(f32(f32(f32(v["fx"]) * r) * f32(cs_)) + f32(v["cx"]))
+            w = f32(f32(f32(f32(v["fy"]) * r) * f32(s_)) + f32(v["cy"]))
     if u < f32(v["min_x"]) or u > f32(v["max_x"]) or w < f32(v["min_y"]) or w > f32(v["max_y"]):
         return o, xr
     o["projX"], o["projY"] = u, w
@@ -89,9 +106,10 @@ def test_spec_logf_pin_and_accuracy():
     assert O.spec_logf(0.0) == -math.inf and O.spec_logf(-1.0) == -math.inf
 
 
-def test_oracle_frustum_matches_restatement():
+@pytest.mark.parametrize("kb8", [False, True])
+def test_oracle_frustum_matches_restatement(kb8):
     F = O.Frustum()
-    v = FS.fill_frustum(F, ON, seed=3)
+    v = FS.fill_frustum(F, ON, seed=3, kb8=kb8)
     pts = FS.world_points(1500, O.WP_DTYPE, OP, seed=4)
     out, xr = O.is_in_frustum(F, pts)
     assert 0.15 < out["inView"].mean() < 0.9
@@ -104,14 +122,14 @@ def test_oracle_frustum_matches_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,seed", [(1, 0), (257, 1), (5000, 2), (100000, 3)])
-def test_gpu_frustum_matches_oracle(built, n, seed):
+@pytest.mark.parametrize("n,seed,kb8", [(1, 0, False), (257, 1, False), (5000, 2, False), (100000, 3, False), (20000, 4, True)])
+def test_gpu_frustum_matches_oracle(built, n, seed, kb8):
     import orbfe
     e = orbfe.ORBextractor(500, 2000, 1.2, 8, 20, 7, 320, 240)
     m = orbfe.ORBmatcher(e)
     Fo, Fp = O.Frustum(), orbfe.Frustum()
-    FS.fill_frustum(Fo, ON, seed=seed)
-    FS.fill_frustum(Fp, PN, seed=seed)
+    FS.fill_frustum(Fo, ON, seed=seed, kb8=kb8)
+    FS.fill_frustum(Fp, PN, seed=seed, kb8=kb8)
     pts = FS.world_points(n, O.WP_DTYPE, OP, seed=seed + 10)
     ref, ref_xr = O.is_in_frustum(Fo, pts)
     out, xr = m.isInFrustum_batch(Fp, pts.view(orbfe.WP_DTYPE))
@@ -119,7 +137,7 @@ def test_gpu_frustum_matches_oracle(built, n, seed):
     assert xr.tobytes() == ref_xr.tobytes()
     o0, _ = m.isInFrustum_batch(Fp, pts[:0].view(orbfe.WP_DTYPE))
     assert len(o0) == 0
-    Fp.camera_model = 1
+    Fp.camera_model = 7
     with pytest.raises(orbfe.OrbfeError):
         m.isInFrustum_batch(Fp, pts.view(orbfe.WP_DTYPE))
 
