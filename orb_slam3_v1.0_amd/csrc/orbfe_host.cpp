@@ -554,7 +554,13 @@ int orbfe_extract_batch(orbfe_handle* h, const uint8_t* const* grays, int pitch,
                 }
             }
         }
-        if (h->useGraph) HIPCHK(h, hipGraphLaunch(h->graphs[batch], s));
+        if (h->useGraph) {
+            HIPCHK(h, hipGraphLaunch(h->graphs[batch], s));
+            h->lastGray = h->dIn;  // what extract_chain records on a plain launch (pyramid / candidate getters)
+            h->lastStride = inFrame;
+            h->lastPitch = h->dInPitch;
+            h->lastBatch = batch;
+        }
     }
     if (!h->useGraph || h->timing) {
         rc = extract_host_enqueue(h, batch, s);
