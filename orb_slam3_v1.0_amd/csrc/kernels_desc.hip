@@ -9,7 +9,8 @@
 //  * orientation on the UNBLURRED level: lanes 0..30 take column u = lane-15 of row +v, lanes
 //    32..62 the same column of row -v; integer moments, wave butterfly reduction (exact).
 //  * descriptor on the BLURRED level: lane i evaluates pattern pairs i, 64+i, 128+i, 192+i; each
-//    __ballot() is 8 descriptor bytes (bit k of byte t == pair 8t+k, Orb_gpu.cu:331-349).
+//    __ballot() is 8 descriptor bytes (bit k of byte t == pair 8t+k, Orb_gpu.cu:331-349).  The 39 x 39
+//    sample window of an interior keypoint is staged in a wave-private LDS tile first.
 //  * samples outside the level image follow BORDER_REFLECT_101 (SPEC DECISION S3).
 //  * atan2 / cos / sin: SPEC DECISION S5 (device_math.h); rounding of the rotated sample offsets is
 //    round-half-even (__float2int_rn == rintf, Orb_gpu.cu:313-314), no FMA contraction.
@@ -20,7 +21,7 @@
 
 namespace orbfe {
 
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "brief_pattern.inc"
 };
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
@@ -145,26 +146,56 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     const float angle = atan2_deg((float)m01, (float)m10);
 
     // ---- steered BRIEF ----
+    // The 512 rotated sample positions of a keypoint fall in a 39 x 39 window (reach <= 18.4 px).  For interior
+    // keypoints the window is staged into a wave-private LDS tile with eight coalesced dword loads (39 rows x 12
+    // dwords) and the 8 samples per lane become LDS byte reads: a 64-lane byte gather from global memory touches
+    // ~30 cache lines per instruction, the staged rows ~6.  Border keypoints keep the direct (reflected) path.
     float a, b;
     cos_sin_deg(angle, a, b);
-    int t0[4], t1[4];
+    constexpr int kPatchRows = 39, kPatchDw = 12;
+    __shared__ uint32_t sPatch[4][kPatchRows * kPatchDw];
+    const int wvb = threadIdx.x >> 6;
+    const int xs = (x - 19) & ~3;                       // dword-aligned left edge of the staged rows
+    const bool staged = inner && xs + 4 * kPatchDw <= bpitch;  // the blurred levels live in the workspace: 64-B aligned rows
+    if (staged) {
+        const uint8_t* prow = blur + (y - 19) * bpitch + xs;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {  // 8 independent sample loads in flight (rotated reach <= 18.4 px)
-        const int pair = q * 64 + lane;
-        const int8_t* pt = &c_pattern[pair * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        for (int it = 0; it < (kPatchRows * kPatchDw + 63) / 64; it++) {
+            const int e = it * 64 + lane;
+            const int r = (e * 43691) >> 19;            // e / 12 for e < 512
+            const int d = e - r * kPatchDw;
+            if (e < kPatchRows * kPatchDw)
+                sPatch[wvb][e] = *reinterpret_cast<const uint32_t*>(prow + r * bpitch + 4 * d);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // wave-private tile: LDS ops of a wave run in order
+    }
+    const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(sPatch[wvb]);
+    const int cOff = (x - 19) - xs + 19;                // LDS column of the keypoint
+    int t0[4], t1[4];
+    const int32_t* pat32 = reinterpret_cast<const int32_t*>(c_pattern);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // 8 independent sample loads in flight
+        const int32_t pw = pat32[q * 64 + lane];  // x0, y0, x1, y1 of pattern pair q*64+lane as one dword
+        const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff);
+        const float x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
         float r0 = x0 * b; const float r0b = y0 * a; r0 = r0 + r0b;
         float c0 = x0 * a; const float c0b = y0 * b; c0 = c0 - c0b;
         float r1 = x1 * b; const float r1b = y1 * a; r1 = r1 + r1b;
         float c1 = x1 * a; const float c1b = y1 * b; c1 = c1 - c1b;
-        int ya = y + __float2int_rn(r0), xa = x + __float2int_rn(c0);
-        int yb = y + __float2int_rn(r1), xb = x + __float2int_rn(c1);
-        if (!inner) {
-            ya = reflect_near(ya, h); xa = reflect_near(xa, w);
-            yb = reflect_near(yb, h); xb = reflect_near(xb, w);
+        const int dya = __float2int_rn(r0), dxa = __float2int_rn(c0);
+        const int dyb = __float2int_rn(r1), dxb = __float2int_rn(c1);
+        if (staged) {
+            t0[q] = pbytes[(dya + 19) * (4 * kPatchDw) + dxa + cOff];
+            t1[q] = pbytes[(dyb + 19) * (4 * kPatchDw) + dxb + cOff];
+        } else {
+            int ya = y + dya, xa = x + dxa, yb = y + dyb, xb = x + dxb;
+            if (!inner) {
+                ya = reflect_near(ya, h); xa = reflect_near(xa, w);
+                yb = reflect_near(yb, h); xb = reflect_near(xb, w);
+            }
+            t0[q] = blur[ya * bpitch + xa];  // level pixels < 2^24: 32-bit offsets
+            t1[q] = blur[yb * bpitch + xb];
         }
-        t0[q] = blur[ya * bpitch + xa];  // level pixels < 2^24: 32-bit offsets
-        t1[q] = blur[yb * bpitch + xb];
     }
     unsigned long long bits[4];
 #pragma unroll
