@@ -47,7 +47,7 @@ namespace {
 
 constexpr int kClaimFree = 0x7fffffff;
 constexpr int kResolveThreads = 1024;
-constexpr int kTopK = 16;         // stored candidates per map point
+constexpr int kTopK = 24;         // stored candidates per map point
 constexpr uint32_t kKey32None = 0xffffffffu;
 constexpr int kRankBits = 20;
 constexpr uint32_t kRankMask = (1u << kRankBits) - 1u;
@@ -84,7 +84,7 @@ struct ProjArgs {
     int* colStart;                // [B][tabLevels][cols + 1]: first storage slot of (level, grid column cx)
     int tabLevels;                // min(nLevels, 32)
     int* cnt;                     // [B][M] number of candidates (dist < 256) per map point
-    uint32_t* topk;               // [B][M][kTopK] sorted smallest keys (one 64-byte line per map point)
+    uint32_t* topk;               // [B][M][kTopK] sorted smallest keys (contiguous per map point)
     int* claimG;                  // [B][kpStride] fallback claim table (frames that do not fit the LDS image)
     int* perm;                    // [B][M] map points ordered by (level, tile): work assignment of the top-K pass
     int* dbg;                     // [B][4] diagnostics: sweeps, cooperative rescans, -, -
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
         else total = topk_scan<false>(A, w, cs, tabStride, rec, descS, &S, segBase, d0, d1, d2, d3, keys);
     }
     A.cnt[(size_t)f * A.M + i] = total;
-    // map-point-major: the 16 keys of one map point are one 64-byte line (i is a permuted index: entry-major
+    // map-point-major: the keys of one map point are contiguous (96 B; i is a permuted index: entry-major
     // 4-byte stores would dirty 16 different sectors per map point)
     uint4* dst = reinterpret_cast<uint4*>(A.topk + ((size_t)f * A.M + i) * kTopK);
 #pragma unroll
