@@ -184,7 +184,7 @@ __device__ __forceinline__ void block_sort_keys(unsigned long long* sKeys, unsig
 constexpr int kCellBits = 22;  // kMaxCells
 
 template <bool LDS>
-__global__ __launch_bounds__(1024) void proj_grid_kernel(ProjArgs A)
+__device__ __forceinline__ void proj_grid_body(const ProjArgs& A)
 {
     __shared__ unsigned long long sKeys[LDS ? kSortLds : 1];
     __shared__ int sRankOf[LDS ? kSortLds : 1];
@@ -289,7 +289,7 @@ __device__ __forceinline__ int sort_bucket(const ProjArgs& A, const orbfe_map_po
     return (lvl * kTilesY + ty) * kTilesX + tx;
 }
 
-__global__ __launch_bounds__(1024) void proj_sort_kernel(ProjArgs A)
+__device__ __forceinline__ void proj_sort_body(const ProjArgs& A)
 {
     __shared__ int sHist[kSortBuckets];
     const int f = blockIdx.x;
@@ -311,6 +311,18 @@ __global__ __launch_bounds__(1024) void proj_sort_kernel(ProjArgs A)
     for (int i = tid; i < A.M; i += 1024) {
         const int pos = atomicAdd(&sHist[sort_bucket(A, mps[i])], 1);
         A.perm[(size_t)f * A.M + pos] = i;
+    }
+}
+
+// One block per frame prepares both sides of the search: the keypoint grid (visit-order sort, level-major storage,
+// column-start tables) and, for SearchByProjection, the (level, tile) order of the map points.
+template <bool LDS, bool SORT_MPS>
+__global__ __launch_bounds__(1024) void proj_prepare_kernel(ProjArgs A)
+{
+    proj_grid_body<LDS>(A);
+    if constexpr (SORT_MPS) {
+        __syncthreads();
+        proj_sort_body(A);
     }
 }
 
@@ -788,16 +800,19 @@ int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::st
 
 int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
 {
-    if (A.kpStride <= kSortLds)
-        hipLaunchKernelGGL(proj_grid_kernel<true>, dim3(A.B), dim3(1024), 0, s, A);
-    else
-        hipLaunchKernelGGL(proj_grid_kernel<false>, dim3(A.B), dim3(1024), 0, s, A);
     if (A.M == 0) {
+        if (A.kpStride <= kSortLds)
+            hipLaunchKernelGGL((proj_prepare_kernel<true, false>), dim3(A.B), dim3(1024), 0, s, A);
+        else
+            hipLaunchKernelGGL((proj_prepare_kernel<false, false>), dim3(A.B), dim3(1024), 0, s, A);
         MCHK(hipMemsetAsync(A.nMatches, 0, (size_t)A.B * sizeof(int), s));
         return ORBFE_OK;
     }
     MCHK(hipMemsetAsync(A.dbg, 0, (size_t)A.B * 4 * sizeof(int), s));
-    hipLaunchKernelGGL(proj_sort_kernel, dim3(A.B), dim3(1024), 0, s, A);
+    if (A.kpStride <= kSortLds)
+        hipLaunchKernelGGL((proj_prepare_kernel<true, true>), dim3(A.B), dim3(1024), 0, s, A);
+    else
+        hipLaunchKernelGGL((proj_prepare_kernel<false, true>), dim3(A.B), dim3(1024), 0, s, A);
     hipLaunchKernelGGL(proj_topk_kernel, dim3((A.M + 255) / 256, A.B), dim3(256), 0, s, A);
     if (A.kpStride <= kResN)  // nKp[f] <= kpStride: the whole frame fits the LDS image
         hipLaunchKernelGGL(proj_resolve_kernel<true>, dim3(A.B), dim3(kResolveThreads), 0, s, A);
@@ -959,9 +974,9 @@ int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, 
     A.scaleFactors = reinterpret_cast<const float*>(dp + oSf);
     A.matchOut = reinterpret_cast<int*>(dp + oMatch);
     if (n <= kSortLds)
-        hipLaunchKernelGGL(proj_grid_kernel<true>, dim3(1), dim3(1024), 0, s, A);
+        hipLaunchKernelGGL((proj_prepare_kernel<true, false>), dim3(1), dim3(1024), 0, s, A);
     else
-        hipLaunchKernelGGL(proj_grid_kernel<false>, dim3(1), dim3(1024), 0, s, A);
+        hipLaunchKernelGGL((proj_prepare_kernel<false, false>), dim3(1), dim3(1024), 0, s, A);
     int* dBest = reinterpret_cast<int*>(dp + oBest);
     hipLaunchKernelGGL(fuse_search_kernel, dim3((M + 255) / 256), dim3(256), 0, s, A, *F, th, M,
                        reinterpret_cast<const orbfe_world_point*>(dp + oPts), dp + oMpDesc,
