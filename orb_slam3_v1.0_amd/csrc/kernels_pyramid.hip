@@ -60,20 +60,34 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
     if (staged) {
         // thread (c4, r) grid over the footprint: 64 dword columns x 4 rows per pass, no division
         const int c4l = tid & 63, rl = tid >> 6;
-        for (int r = rl; r < nrows; r += 4) {
-            const uint8_t* row = s + (size_t)(sy0 + r) * spitch;
-            for (int c4 = c4l; c4 < ndw; c4 += 64) {
-                const int gx = sx0 + 4 * c4;
-                uint32_t wv;
-                if (srcAligned4 && gx + 3 < sw) {
-                    wv = *reinterpret_cast<const uint32_t*>(row + gx);
-                } else {
-                    wv = 0;
+        if (srcAligned4 && ndw <= 64) {
+            // aligned source (always true for the workspace levels): whole dwords, and ALL loads of a thread are
+            // issued before the first LDS store (a load / store pair per loop iteration would serialise the
+            // global-memory latency up to ten times).  Bytes past the row end lie inside the pitch and are never
+            // addressed by the tables.
+            constexpr int kPass = kRsMaxRows / 4;
+            const bool cok = c4l < ndw;
+            const uint8_t* p0 = s + (size_t)(sy0 + rl) * spitch + sx0 + 4 * c4l;
+            uint32_t wv[kPass];
+#pragma unroll
+            for (int k = 0; k < kPass; k++) {
+                wv[k] = 0;
+                if (cok && rl + 4 * k < nrows) wv[k] = *reinterpret_cast<const uint32_t*>(p0 + (size_t)(4 * k) * spitch);
+            }
+#pragma unroll
+            for (int k = 0; k < kPass; k++)
+                if (cok && rl + 4 * k < nrows) *reinterpret_cast<uint32_t*>(&sSrc[rl + 4 * k][4 * c4l]) = wv[k];
+        } else {
+            for (int r = rl; r < nrows; r += 4) {
+                const uint8_t* row = s + (size_t)(sy0 + r) * spitch;
+                for (int c4 = c4l; c4 < ndw; c4 += 64) {
+                    const int gx = sx0 + 4 * c4;
+                    uint32_t wv = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                         if (gx + i < sw) wv |= (uint32_t)row[gx + i] << (8 * i);
+                    *reinterpret_cast<uint32_t*>(&sSrc[r][4 * c4]) = wv;
                 }
-                *reinterpret_cast<uint32_t*>(&sSrc[r][4 * c4]) = wv;
             }
         }
         __syncthreads();
