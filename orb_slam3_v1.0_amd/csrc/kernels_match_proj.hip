@@ -360,10 +360,17 @@ __device__ __forceinline__ int topk_scan(const ProjArgs& A, const MpWindow& w, c
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {  // levels that pass src/Frame.cc:437-452 (at most two)
+        int4 qn = make_int4(0, 0, 0, 0);  // record of the next slot, requested one iteration ahead
+        if (plo[k] < phi[k]) {
+            if constexpr (LDS) qn = S->rec[plo[k] - segBase];
+            else qn = rec[plo[k]];
+        }
         for (int p = plo[k]; p < phi[k]; p++) {
-            int4 q;
-            if constexpr (LDS) q = S->rec[p - segBase];
-            else q = rec[p];
+            const int4 q = qn;
+            if (p + 1 < phi[k]) {
+                if constexpr (LDS) qn = S->rec[p + 1 - segBase];
+                else qn = rec[p + 1];
+            }
             const int cy = q.y >> 8;
             if (cy < w.minCY || cy > w.maxCY) continue;
             const float dx = __int_as_float(q.z) - w.x, dy = __int_as_float(q.w) - w.y;
@@ -423,8 +430,40 @@ __global__ __launch_bounds__(256) void proj_topk_kernel(ProjArgs A)
     }
     const bool useLds = segEnd - segBase <= kTopkLds;  // block-uniform
     if (useLds) {
-        for (int j = threadIdx.x; j < segEnd - segBase; j += 256) S.rec[j] = rec[segBase + j];
-        for (int j = threadIdx.x; j < (segEnd - segBase) * 4; j += 256) S.desc[0][j] = descS[(size_t)segBase * 4 + j];
+        // records and descriptors of the segment are contiguous: 48 B per keypoint as 3 x 16-byte pieces, four
+        // loads in flight per thread before the LDS stores (a load / store pair per iteration would serialise
+        // the global latency)
+        const int nSeg = segEnd - segBase;
+        const uint4* gRec = reinterpret_cast<const uint4*>(rec + segBase);
+        const uint4* gDesc = reinterpret_cast<const uint4*>(descS + (size_t)segBase * 4);
+        uint4* lRec = reinterpret_cast<uint4*>(S.rec);
+        uint4* lDesc = reinterpret_cast<uint4*>(&S.desc[0][0]);
+        for (int j0 = 0; j0 < nSeg * 2; j0 += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                if (j < nSeg * 2) v[k] = gDesc[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                if (j < nSeg * 2) lDesc[j] = v[k];
+            }
+        }
+        for (int j0 = 0; j0 < nSeg; j0 += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                if (j < nSeg) v[k] = gRec[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                if (j < nSeg) lRec[j] = v[k];
+            }
+        }
     }
     __syncthreads();
     if (!live) return;
