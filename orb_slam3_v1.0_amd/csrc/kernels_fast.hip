@@ -66,10 +66,10 @@ __device__ __forceinline__ bool compass_pass_ptr(const uint8_t* p, int th)
     // the compass cycle 0-4-8-12 is bipartite ({0,8} vs {4,12}) and every cross pair is adjacent, so
     // "some adjacent pair is bright" == (0 or 8 bright) and (4 or 12 bright); same for dark
     const int v = p[0];
-    const int d0 = p[3 * kImgW] - v, d4 = p[3] - v, d8 = p[-3 * kImgW] - v, d12 = p[-3] - v;
-    const int hiPair = min(max(d0, d8), max(d4, d12));
-    const int loPair = max(min(d0, d8), min(d4, d12));
-    return hiPair > th || loPair < -th;
+    const int a0 = p[3 * kImgW], a4 = p[3], a8 = p[-3 * kImgW], a12 = p[-3];
+    const int hiPair = min(max(a0, a8), max(a4, a12));  // thresholds move to the centre value: no per-point subtraction
+    const int loPair = max(min(a0, a8), min(a4, a12));
+    return hiPair > v + th || loPair < v - th;
 }
 
 __device__ __forceinline__ void ring_diffs(const uint8_t (*img)[kImgW], int r, int c, int (&d)[16])
