@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the all-cores CPU baseline (0/1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the RCCL result gather even at N=1 (a 1-rank process group): exercises the N>1 code path on one GPU")
     ap.add_argument("--no-match", action="store_true", help="extract only")
     ap.add_argument("--no-overlap", action="store_true", help="match on the extraction stream (no 2-stream pipelining)")
     a = ap.parse_args()
@@ -162,10 +164,11 @@ def main():
     # default stream's handle is 0, which the C ABI reads as "use the handle's own stream"
     torch.cuda.set_stream(torch.cuda.Stream(dev))
     dist = None
-    if world > 1:
+    if world > 1 or a.force_gather:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import orbfe
@@ -193,7 +196,7 @@ def main():
                          match=torch.full((B, cap), -1, dtype=torch.int32, device=dev),
                          nmatch=torch.zeros(B, dtype=torch.int32, device=dev),
                          ev_ext=torch.cuda.Event(), ev_done=torch.cuda.Event()))
-    gather = world > 1 and not a.no_gather
+    gather = (world > 1 or a.force_gather) and not a.no_gather
     if gather:
         pack = torch.zeros((B, cap, 60), dtype=torch.uint8, device=dev)  # kp 24 + desc 32 + match 4
         g_out = torch.zeros((world * B, cap, 60), dtype=torch.uint8, device=dev)  # rank-major concatenation
