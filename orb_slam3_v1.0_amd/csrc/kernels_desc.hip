@@ -40,6 +40,12 @@ __device__ __forceinline__ int wave_sum(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// first storage slot of every level in the per-frame level-keypoint array (LevelDesc::kpBase), by value in the
+// kernel arguments so that a wave knows its level without touching memory
+struct KpBaseTab {
+    int base[kMaxLevels + 1];
+};
+
 __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* __restrict__ P,
                                                            const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
                                                            int gray0Pitch, const uint8_t* __restrict__ ws,
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
                                                            orbfe_keypoint* __restrict__ kpOut,
                                                            uint8_t* __restrict__ descOut, int* __restrict__ nOut,
                                                            int* __restrict__ perLevelOut, int* __restrict__ statusOut,
-                                                           int frames, int slotBlocks)
+                                                           int frames, int slotBlocks, KpBaseTab tab)
 {
     // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, so XCD x gets linear ids x, x+8, ...;
     // give it the frames x, x+8, ... ONE AFTER THE OTHER (all keypoint blocks of a frame are consecutive on its
@@ -61,24 +67,25 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     const int f = fgrp * 8 + xcd;
     if (f >= frames) return;
     const int lane = threadIdx.x & 63;
-    const int slot = sb * 4 + (threadIdx.x >> 6);  // output index within the frame
+    // One wave per STORAGE slot of the per-frame level-keypoint array: its level is static (table in the kernel
+    // arguments), so the keypoint word is requested at once, in parallel with the per-level counts; the count of its
+    // own level says whether the slot is occupied, the counts of the lower levels give the output position
+    // (levels are concatenated in order: keypointsAcc, ORBextractor.cc:499-500).  Two dependent memory round trips
+    // lead to the pixel loads instead of four.
+    const int sslot = __builtin_amdgcn_readfirstlane(sb * 4 + (int)(threadIdx.x >> 6));
     const int nL = P->nLevels;
+    const uint32_t kw = lvlKp[(size_t)f * P->kpCapFrame + min(sslot, P->kpCapFrame - 1)];
     const uint32_t* cnt = counters + (size_t)f * nL * kCntWords;
-
-    // locate (level, j): levels are concatenated in order (keypointsAcc, ORBextractor.cc:499-500)
-    int l = 0, base = 0, total = 0;
-    bool found = false;
-    int lv = 0, j = 0;
-    for (l = 0; l < nL; l++) {
+    int lv = 0;
+    for (int l = 1; l < nL; l++) lv = sslot >= tab.base[l] ? l : lv;
+    const int j = sslot - tab.base[lv];
+    int before = 0, total = 0, mine = 0;
+    for (int l = 0; l < nL; l++) {
         const int c = (int)cnt[l * kCntWords + kCntKp];
-        if (!found && slot < total + c) {
-            found = true;
-            lv = l;
-            j = slot - total;
-        }
+        before += l < lv ? c : 0;
+        mine = l == lv ? c : mine;
         total += c;
     }
-    (void)base;
     if (sb == 0 && threadIdx.x == 0) {
         nOut[f] = total;
         if (perLevelOut)
@@ -89,10 +96,17 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
             statusOut[f] = (int)st;
         }
     }
-    if (!found) return;
+    if (sslot >= P->kpCapFrame || j >= mine) return;
+    const int slot = before + j;  // output index within the frame
 
+    // the four pattern dwords of this lane do not depend on the keypoint: request them now
+    int32_t pwq[4];
+    {
+        const int32_t* pat32 = reinterpret_cast<const int32_t*>(c_pattern);
+#pragma unroll
+        for (int q = 0; q < 4; q++) pwq[q] = pat32[q * 64 + lane];
+    }
     const LevelDesc& L = P->lv[lv];
-    const uint32_t kw = lvlKp[(size_t)f * P->kpCapFrame + L.kpBase + j];
     const int x = cand_x(kw), y = cand_y(kw), resp = cand_score(kw);
     const int w = L.w, h = L.h;
 
@@ -112,6 +126,26 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     // 16) never touch the border: their sample addresses need no reflection.  One keypoint per wave, so the choice
     // is wave-uniform.
     const bool inner = x >= 19 && x < w - 19 && y >= 19 && y < h - 19;
+
+    // the 39 x 39 BRIEF window does not depend on the angle: its rows are requested here, together with the
+    // orientation patch, and land in LDS after the angle is known
+    constexpr int kPatchRows = 39, kPatchDw = 12, kStageIters = (kPatchRows * kPatchDw + 63) / 64;
+    __shared__ uint32_t sPatch[4][kPatchRows * kPatchDw];
+    const int wvb = threadIdx.x >> 6;
+    const int xs = (x - 19) & ~3;                       // dword-aligned left edge of the staged rows
+    const bool staged = inner && xs + 4 * kPatchDw <= bpitch;  // the blurred levels live in the workspace: 64-B aligned rows
+    uint32_t stg[kStageIters];
+    if (staged) {
+        const uint8_t* prow = blur + (y - 19) * bpitch + xs;
+#pragma unroll
+        for (int it = 0; it < kStageIters; it++) {
+            const int e = it * 64 + lane;
+            const int r = (e * 43691) >> 19;            // e / 12 for e < 512
+            const int d = e - r * kPatchDw;
+            stg[it] = 0;
+            if (e < kPatchRows * kPatchDw) stg[it] = *reinterpret_cast<const uint32_t*>(prow + r * bpitch + 4 * d);
+        }
+    }
 
     // ---- IC angle ----
     const int u = (lane & 31) - kHalfPatch;   // -15..16 (16 == idle lane 31/63)
@@ -152,30 +186,20 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     // ~30 cache lines per instruction, the staged rows ~6.  Border keypoints keep the direct (reflected) path.
     float a, b;
     cos_sin_deg(angle, a, b);
-    constexpr int kPatchRows = 39, kPatchDw = 12;
-    __shared__ uint32_t sPatch[4][kPatchRows * kPatchDw];
-    const int wvb = threadIdx.x >> 6;
-    const int xs = (x - 19) & ~3;                       // dword-aligned left edge of the staged rows
-    const bool staged = inner && xs + 4 * kPatchDw <= bpitch;  // the blurred levels live in the workspace: 64-B aligned rows
     if (staged) {
-        const uint8_t* prow = blur + (y - 19) * bpitch + xs;
 #pragma unroll
-        for (int it = 0; it < (kPatchRows * kPatchDw + 63) / 64; it++) {
+        for (int it = 0; it < kStageIters; it++) {
             const int e = it * 64 + lane;
-            const int r = (e * 43691) >> 19;            // e / 12 for e < 512
-            const int d = e - r * kPatchDw;
-            if (e < kPatchRows * kPatchDw)
-                sPatch[wvb][e] = *reinterpret_cast<const uint32_t*>(prow + r * bpitch + 4 * d);
+            if (e < kPatchRows * kPatchDw) sPatch[wvb][e] = stg[it];
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // wave-private tile: LDS ops of a wave run in order
     }
     const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(sPatch[wvb]);
     const int cOff = (x - 19) - xs + 19;                // LDS column of the keypoint
     int t0[4], t1[4];
-    const int32_t* pat32 = reinterpret_cast<const int32_t*>(c_pattern);
 #pragma unroll
     for (int q = 0; q < 4; q++) {  // 8 independent sample loads in flight
-        const int32_t pw = pat32[q * 64 + lane];  // x0, y0, x1, y1 of pattern pair q*64+lane as one dword
+        const int32_t pw = pwq[q];  // x0, y0, x1, y1 of pattern pair q*64+lane as one dword (requested at kernel entry)
         const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff);
         const float x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
         float r0 = x0 * b; const float r0b = y0 * a; r0 = r0 + r0b;
@@ -225,13 +249,15 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
 void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const PipelineDesc* dP, const uint8_t* gray0,
                          size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws, const uint32_t* counters,
                          const uint32_t* lvlKp, orbfe_keypoint* kpOut, uint8_t* descOut, int* nOut,
-                         int* perLevelOut, int* statusOut)
+                         int* perLevelOut, int* statusOut, const int* kpBase, int nLevels)
 {
+    KpBaseTab tab{};
+    for (int l = 0; l < nLevels; l++) tab.base[l] = kpBase[l];
     dim3 block(256);
     const int slotBlocks = (kpCapFrame + 3) / 4;
     dim3 grid((unsigned)(((frames + 7) / 8) * 8 * slotBlocks));
     hipLaunchKernelGGL(orient_brief_kernel, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch, ws,
-                       counters, lvlKp, kpOut, descOut, nOut, perLevelOut, statusOut, frames, slotBlocks);
+                       counters, lvlKp, kpOut, descOut, nOut, perLevelOut, statusOut, frames, slotBlocks, tab);
 }
 
 }  // namespace orbfe

@@ -27,6 +27,6 @@ void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, con
 void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const PipelineDesc* dP, const uint8_t* gray0,
                          size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws, const uint32_t* counters,
                          const uint32_t* lvlKp, orbfe_keypoint* kpOut, uint8_t* descOut, int* nOut,
-                         int* perLevelOut, int* statusOut);
+                         int* perLevelOut, int* statusOut, const int* kpBase, int nLevels);
 
 }  // namespace orbfe

@@ -467,8 +467,10 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
     launch_quadtree(s, batch, nL, h->maxNodeCap, h->dP, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, d_gray, frame_stride,
                     pitch, h->ws, h->dTileRows, h->dQtScratch);
     if (ev) HIPCHK(h, hipEventRecord(ev[3], s));
+    int kpBase[kMaxLevels];
+    for (int l = 0; l < nL; l++) kpBase[l] = P.lv[l].kpBase;
     launch_orient_brief(s, batch, P.kpCapFrame, h->dP, d_gray, frame_stride, pitch, h->ws, h->dCounters, h->dLvlKp,
-                        d_kp, d_desc, d_n, d_per, d_status);
+                        d_kp, d_desc, d_n, d_per, d_status, kpBase, nL);
     if (ev) HIPCHK(h, hipEventRecord(ev[4], s));
     HIPCHK(h, hipGetLastError());
     h->lastGray = d_gray;
