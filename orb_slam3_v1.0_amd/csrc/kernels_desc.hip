@@ -76,16 +76,31 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     const int nL = P->nLevels;
     const uint32_t kw = lvlKp[(size_t)f * P->kpCapFrame + min(sslot, P->kpCapFrame - 1)];
     const uint32_t* cnt = counters + (size_t)f * nL * kCntWords;
+    // the first 8 levels with constant indices: one s_load for the table, 8 independent scalar loads for the counts
+    // (a runtime-bounded loop would wait for every load in turn); deeper pyramids finish in the loops below
     int lv = 0;
-    for (int l = 1; l < nL; l++) lv = sslot >= tab.base[l] ? l : lv;
-    const int j = sslot - tab.base[lv];
-    int before = 0, total = 0, mine = 0;
-    for (int l = 0; l < nL; l++) {
+#pragma unroll
+    for (int l = 1; l < 8; l++) lv = (l < nL && sslot >= tab.base[l]) ? l : lv;
+    for (int l = 8; l < nL; l++) lv = sslot >= tab.base[l] ? l : lv;
+    int c8[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) c8[l] = l < nL ? (int)cnt[l * kCntWords + kCntKp] : 0;
+    int before = 0, total = 0, mine = 0, baseLv = 0;
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        before += l < lv ? c8[l] : 0;
+        mine = l == lv ? c8[l] : mine;
+        baseLv = l == lv ? tab.base[l] : baseLv;
+        total += c8[l];
+    }
+    for (int l = 8; l < nL; l++) {
         const int c = (int)cnt[l * kCntWords + kCntKp];
         before += l < lv ? c : 0;
         mine = l == lv ? c : mine;
+        baseLv = l == lv ? tab.base[l] : baseLv;
         total += c;
     }
+    const int j = sslot - baseLv;
     if (sb == 0 && threadIdx.x == 0) {
         nOut[f] = total;
         if (perLevelOut)
