@@ -113,3 +113,39 @@ def test_extract_rejects_bad_arguments(built):
     ptrs = (C.c_void_p * 3)(img.ctypes.data, img.ctypes.data, img.ctypes.data)
     assert L.orbfe_extract_batch(ex.h, ptrs, 320, 3, kp.ctypes.data, desc.ctypes.data, C.byref(n), None) == 1  # batch > max_batch
     assert L.orbfe_get_pyramid_level(ex.h, 0, 99, 0, kp.ctypes.data, 320) == 1
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_plain_launches(built):
+    """The host-pointer extract call is replayed as a captured hipGraph; with stage timing on it takes the plain-launch
+    path.  Both must give identical results, for alternating batch sizes and images, including the pyramid getter."""
+    import orbfe
+    from orbfe import synth
+    W, H = 320, 240
+    ex = orbfe.ORBextractor(600, 8000, 1.2, 6, 20, 7, W, H, device=0, max_batch=3)
+    imgs = [synth.frame(W, H, i) for i in range(5)]
+
+    def run_all():
+        out = []
+        for i, im in enumerate(imgs):
+            out.append(ex.extractFeatures(im))
+            lvl = ex.pyramid_level(2, True, 0)
+            out.append((lvl.copy(),))
+            if i % 2 == 0:
+                out.append(ex.extract_batch([imgs[i], imgs[(i + 1) % 5], imgs[(i + 2) % 5]]))
+        return out
+
+    a = run_all()               # captures graphs for batch 1 and 3, then replays
+    b = run_all()               # replays only
+    ex.set_stage_timing(True)   # plain launches with stage events
+    c = run_all()
+    ms, n = ex.stage_ms()
+    ex.set_stage_timing(False)
+    assert n > 0 and ms["total"] > 0
+
+    def same(u, v):
+        if isinstance(u, (tuple, list)):
+            return len(u) == len(v) and all(same(x, y) for x, y in zip(u, v))
+        return np.array_equal(np.asarray(u), np.asarray(v))
+
+    assert same(a, b) and same(a, c)
