@@ -60,11 +60,13 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     // give it the frames x, x+8, ... ONE AFTER THE OTHER (all keypoint blocks of a frame are consecutive on its
     // XCD): the two level images a frame's patches gather from (about 2 MB) then stay in that XCD's 4 MB L2 while
     // its ~1000 keypoints are processed, instead of 32 frames thrashing it.
-    const int xcd = blockIdx.x & 7;
-    const int q8 = blockIdx.x >> 3;
+    // (fewer than 8 frames: plain frame-major order, no idle blocks)
+    const int G = frames >= 8 ? 8 : 1;
+    const int xcd = G == 8 ? (int)(blockIdx.x & 7) : 0;
+    const int q8 = G == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int fgrp = q8 / slotBlocks;
     const int sb = q8 - fgrp * slotBlocks;
-    const int f = fgrp * 8 + xcd;
+    const int f = fgrp * G + xcd;
     if (f >= frames) return;
     const int lane = threadIdx.x & 63;
     // One wave per STORAGE slot of the per-frame level-keypoint array: its level is static (table in the kernel
@@ -270,7 +272,7 @@ void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const Pipeli
     for (int l = 0; l < nLevels; l++) tab.base[l] = kpBase[l];
     dim3 block(256);
     const int slotBlocks = (kpCapFrame + 3) / 4;
-    dim3 grid((unsigned)(((frames + 7) / 8) * 8 * slotBlocks));
+    dim3 grid((unsigned)((frames >= 8 ? ((frames + 7) / 8) * 8 : frames) * slotBlocks));
     hipLaunchKernelGGL(orient_brief_kernel, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch, ws,
                        counters, lvlKp, kpOut, descOut, nOut, perLevelOut, statusOut, frames, slotBlocks, tab);
 }
