@@ -318,12 +318,25 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
         // 1. child counts
         for (int i = tid; i < n * 4; i += kQtThreads) sCC[i] = 0;
         __syncthreads();
-        for (int p = tid; p < cL; p += kQtThreads) {
-            const uint32_t cw = C[p];
-            const int wgt = PT_WEIGHT(cw);
-            if (wgt) {
-                const int i = nodeOf[p];
-                if (ncnt[i] > 1) atomicAdd(&sCC[4 * i + child_code(box[i], cand_x(cw), cand_y(cw))], wgt);
+        // (four candidate words and node labels in flight per thread: the passes over the candidates are
+        // latency-bound, and a load / use pair per iteration would wait for every L2 round trip in turn)
+        for (int p0 = tid; p0 < cL; p0 += 4 * kQtThreads) {
+            uint32_t cw4[4];
+            int nd4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int p = p0 + k * kQtThreads;
+                cw4[k] = p < cL ? C[p] : 0u;
+                nd4[k] = p < cL ? (int)nodeOf[p] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t cw = cw4[k];
+                const int wgt = (p0 + k * kQtThreads < cL) ? PT_WEIGHT(cw) : 0;
+                if (wgt) {
+                    const int i = nd4[k];
+                    if (ncnt[i] > 1) atomicAdd(&sCC[4 * i + child_code(box[i], cand_x(cw), cand_y(cw))], wgt);
+                }
             }
         }
         __syncthreads();
@@ -486,11 +499,23 @@ __global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc
         const int nToExpand = sRed[2];
 
         // 6. re-label the points
-        for (int p = tid; p < cL; p += kQtThreads) {
-            const uint32_t cw = C[p];
-            if (PT_WEIGHT(cw)) {
-                const int i = nodeOf[p];
-                nodeOf[p] = (uint16_t)(sSplit[i] ? sCC[4 * i + child_code(box[i], cand_x(cw), cand_y(cw))] : sKeep[i]);
+        for (int p0 = tid; p0 < cL; p0 += 4 * kQtThreads) {
+            uint32_t cw4[4];
+            int nd4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int p = p0 + k * kQtThreads;
+                cw4[k] = p < cL ? C[p] : 0u;
+                nd4[k] = p < cL ? (int)nodeOf[p] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int p = p0 + k * kQtThreads;
+                const uint32_t cw = cw4[k];
+                if (p < cL && PT_WEIGHT(cw)) {
+                    const int i = nd4[k];
+                    nodeOf[p] = (uint16_t)(sSplit[i] ? sCC[4 * i + child_code(box[i], cand_x(cw), cand_y(cw))] : sKeep[i]);
+                }
             }
         }
         __syncthreads();
