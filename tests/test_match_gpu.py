@@ -124,3 +124,19 @@ def test_descriptor_distance_host(built):
         a = rng.integers(0, 256, 32, dtype=np.uint8)
         b = rng.integers(0, 256, 32, dtype=np.uint8)
         assert orbfe.ORBmatcher.DescriptorDistance(a, b) == O.hamming(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th,nn,M,seed", [(20.0, 0.85, 3000, 11), (6.0, 0.9, 1500, 12)])
+def test_projection_large_frame_paths(built, th, nn, M, seed):
+    """Frames with more than 2048 keypoints take the other code paths: global-memory sort of the visit order,
+    top-K segments that do not fit the LDS tile, claim table in global memory."""
+    orbfe, ex, e, kp, desc = _setup(1280, 720, 5000, 8, 3)
+    assert len(kp) > 2048
+    mps, mpd, init_obs = S.projection_scenario(kp, desc, M, seed, O.MP_DTYPE, NAMES_O, e.nLevels)
+    fvo = O.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, 1280.0, 720.0, e.scaleFactors)
+    n_ref, out_ref = O.search_by_projection(fvo, mps, mpd, init_obs, th, nn)
+    fv = orbfe.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, 1280.0, 720.0, ex.mvScaleFactor)
+    n, out = orbfe.ORBmatcher(ex).SearchByProjection(fv, mps.view(orbfe.MP_DTYPE), mpd, th, False, 0.0, nn, init_obs)
+    assert n == n_ref and np.array_equal(out, out_ref)
+    assert n_ref > M // 10
