@@ -134,16 +134,6 @@ __device__ __forceinline__ void window_cells(const GridDesc& g, MpWindow& w)
     if (w.minCX >= g.cols || w.maxCX < 0 || w.minCY >= g.rows || w.maxCY < 0) w.valid = false;
 }
 
-// the part of GetFeaturesInArea's candidate test that the cell range does not already imply:
-// pyramid level (src/Frame.cc:437-452) and the square window (:457-461)
-__device__ __forceinline__ bool level_and_box(const MpWindow& w, float kx, float ky, int oct)
-{
-    const bool checkLevels = (w.minLevel > 0) || (w.maxLevel >= 0);  // src/Frame.cc:437
-    if (checkLevels && (oct < w.minLevel || (w.maxLevel >= 0 && oct > w.maxLevel))) return false;
-    const float dx = kx - w.x, dy = ky - w.y;
-    return fabsf(dx) < w.r && fabsf(dy) < w.r;  // src/Frame.cc:461
-}
-
 __device__ __forceinline__ uint32_t make_key32(int dist, int rank) { return ((uint32_t)dist << kRankBits) | (uint32_t)rank; }
 
 // ---------------------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ __device__ __forceinline__ void wave_top2(unsigned long long& k1, unsigned long 
     }
 }
 
-static __global__ void fill_kernel(int* p, int v, size_t n)
+[[maybe_unused]] static __global__ void fill_kernel(int* p, int v, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
