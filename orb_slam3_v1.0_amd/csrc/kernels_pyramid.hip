@@ -20,6 +20,9 @@ namespace orbfe {
 constexpr int kRsTW = 128, kRsTH = 16;
 constexpr int kRsMaxRows = 40, kRsMaxCols = 304;
 
+// KPASS = staging passes of 4 rows a thread issues (6 covers footprints up to 24 rows, i.e. level ratios up to 1.375;
+// the host picks 10 for larger ratios)
+template <int KPASS>
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, size_t srcFrameStride,
                                                      int sw, int sh, int spitch, int srcAligned4,
                                                      uint8_t* __restrict__ dst, size_t dstFrameStride,
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
     const int sy1 = min((int)(ytab[tyLast] & 0xffffu) + 1, sh - 1);
     const int nrows = sy1 - sy0 + 1;
     const int ndw = (sx1 - sx0) / 4 + 1;                                          // dwords per staged row
-    const bool staged = nrows <= kRsMaxRows && ndw * 4 <= kRsMaxCols;
+    const bool staged = nrows <= 4 * KPASS && ndw * 4 <= kRsMaxCols;
 
     if (staged) {
         // thread (c4, r) grid over the footprint: 64 dword columns x 4 rows per pass, no division
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
             // issued before the first LDS store (a load / store pair per loop iteration would serialise the
             // global-memory latency up to ten times).  Bytes past the row end lie inside the pitch and are never
             // addressed by the tables.
-            constexpr int kPass = kRsMaxRows / 4;
+            constexpr int kPass = KPASS;
             const bool cok = c4l < ndw;
             const uint8_t* p0 = s + (size_t)(sy0 + rl) * spitch + sx0 + 4 * c4l;
             uint32_t wv[kPass];
@@ -144,8 +147,14 @@ void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFram
 {
     dim3 block(256);
     dim3 grid(frames, (dw + kRsTW - 1) / kRsTW, (dh + kRsTH - 1) / kRsTH);
-    hipLaunchKernelGGL(resize_kernel, grid, block, 0, s, src, srcFrameStride, sw, sh, spitch, srcAligned4, dst,
-                       dstFrameStride, dw, dh, dpitch, xtab, ytab);
+    // largest source footprint of a 16-row tile: 16 output rows span (15 * sh) / dh source rows, + 2 for the taps
+    const int maxRows = (int)(((long long)(kRsTH - 1) * sh + dh - 1) / dh) + 2;
+    if (maxRows <= 24)
+        hipLaunchKernelGGL(resize_kernel<6>, grid, block, 0, s, src, srcFrameStride, sw, sh, spitch, srcAligned4, dst,
+                           dstFrameStride, dw, dh, dpitch, xtab, ytab);
+    else
+        hipLaunchKernelGGL(resize_kernel<kRsMaxRows / 4>, grid, block, 0, s, src, srcFrameStride, sw, sh, spitch, srcAligned4,
+                           dst, dstFrameStride, dw, dh, dpitch, xtab, ytab);
 }
 
 }  // namespace orbfe
