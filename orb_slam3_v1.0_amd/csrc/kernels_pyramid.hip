@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
         }
     };
     if (staged)
-        body([&](int yy, int xx) -> uint32_t { return sSrc[yy - sy0][xx - sx0]; });
+        body([&](int yy, int xx) -> uint32_t {  // 24-bit multiply: the row offset is below 40 * 304
+            return (&sSrc[0][0])[__umul24((uint32_t)(yy - sy0), (uint32_t)kRsMaxCols) + (uint32_t)(xx - sx0)];
+        });
     else
         body([&](int yy, int xx) -> uint32_t { return s[(size_t)yy * spitch + xx]; });
 }
