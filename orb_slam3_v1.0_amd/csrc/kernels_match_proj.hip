@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void proj_prepare_kernel(ProjArgs A)
 // 32-bit keys).  A block owns 256 map points of one frame, ordered by (level, tile): the storage segment
 // of the levels they can match is staged in LDS (records + descriptors, 48 B per keypoint), because the
 // per-lane gathers of this loop are ~8x cheaper from LDS than through the vector L1.
-constexpr int kTopkLds = 1024;  // staged keypoints per block (48 KB -> 3 blocks per CU); larger segments read global memory
+constexpr int kTopkLds = 768;  // staged keypoints per block (36 KB -> 4 blocks per CU); larger segments read global memory
 
 struct TopkLds {
     int4 rec[kTopkLds];
