@@ -1,0 +1,27 @@
+"""Randomised parity sweep (tools/fuzz_extract.py): random image sizes, pyramid depths, scale factors, thresholds and
+budgets; the GPU extractor must equal the oracle bit for bit or refuse the configuration with the documented
+ORBFE_ERR_UNSUPPORTED (portrait images with round(W/H) == 0: the reference divides by zero there)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.gpu
+def test_random_configurations_bit_exact(built):
+    import fuzz_extract as FZ
+    import orbfe
+    rng = np.random.default_rng(2)
+    done = refused = 0
+    for k in range(24):
+        cfg = FZ.random_config(rng)
+        try:
+            FZ.check(cfg, seed=100 + k)
+            done += 1
+        except orbfe.OrbfeError as err:
+            assert err.code == 2 and round(cfg[6] / cfg[7]) == 0, (cfg, str(err))
+            refused += 1
+    assert done >= 15
