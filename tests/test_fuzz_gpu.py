@@ -25,3 +25,13 @@ def test_random_configurations_bit_exact(built):
             assert err.code == 2 and round(cfg[6] / cfg[7]) == 0, (cfg, str(err))
             refused += 1
     assert done >= 15
+
+
+@pytest.mark.gpu
+def test_random_projection_matching_exact(built):
+    """tools/fuzz_match.py: random frame sizes, grids (8x6 ... 257x130), radii, ratios, map-point counts (1 ... 4000),
+    initial claims and far-point filters; match indices must equal the oracle's."""
+    import fuzz_match as FM
+    rng = np.random.default_rng(4)
+    ran = sum(FM.one(rng, k) is not None for k in range(16))
+    assert ran >= 12
