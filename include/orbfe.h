@@ -301,6 +301,14 @@ int orbfe_fuse_search(orbfe_handle *h, const orbfe_frame_view *KF, const float *
                       const orbfe_world_point *points, const uint8_t *mp_desc, int *best_idx_out,
                       int *best_dist_out);
 
+/* replaces the selection loop of MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:343-416; called after every
+ * AddObservation / Fuse, src/LocalMapping.cc) for a batch of map points: set s holds the observed descriptors
+ * desc[set_off[s] .. set_off[s+1]) (32 bytes each, in the order the reference collects them); best_idx_out[s] =
+ * index inside the set of the descriptor with the least median distance to the rest (-1 for an empty set, the
+ * reference returns early); best_median_out may be NULL.  HOST pointers. */
+int orbfe_distinctive_descriptors(orbfe_handle *h, int n_sets, const int *set_off, const uint8_t *desc,
+                                  int *best_idx_out, int *best_median_out);
+
 /* -------------------------------------------------------------------------------------------
  * Vocabulary tree: the per-feature part of Frame::ComputeBoW
  * ---------------------------------------------------------------------------------------- */

@@ -665,3 +665,38 @@ int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const
     for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
     return nmatches;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:343-416) for a batch of map points: set s holds
+ * the observed descriptors desc[setOff[s] .. setOff[s+1]); the representative is the one with the least
+ * MEDIAN Hamming distance to the set, where the median of row i is element (size_t)(0.5 * (N - 1)) of its
+ * sorted distances (the row includes the zero self-distance), first minimum wins (:396-409).
+ * bestIdxOut[s] = index inside the set (-1 for an empty set), bestMedianOut[s] = that median.
+ * ------------------------------------------------------------------------------------------ */
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+void orc_distinctive_descriptors(int nSets, const int *setOff, const uint8_t *desc, int *bestIdxOut,
+                                 int *bestMedianOut)
+{
+    for (int s = 0; s < nSets; s++) {
+        const int N = setOff[s + 1] - setOff[s];
+        bestIdxOut[s] = -1;
+        if (bestMedianOut) bestMedianOut[s] = 0;
+        if (N <= 0) continue;
+        const uint8_t *d = desc + (size_t)setOff[s] * 32;
+        int *row = (int *)malloc(sizeof(int) * (size_t)N);
+        int BestMedian = 0x7fffffff, BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            for (int j = 0; j < N; j++) row[j] = i == j ? 0 : orc_hamming(d + (size_t)i * 32, d + (size_t)j * 32);
+            qsort(row, (size_t)N, sizeof(int), cmp_int);
+            const int median = row[(size_t)(0.5 * (double)(N - 1))];
+            if (median < BestMedian) {
+                BestMedian = median;
+                BestIdx = i;
+            }
+        }
+        free(row);
+        bestIdxOut[s] = BestIdx;
+        if (bestMedianOut) bestMedianOut[s] = BestMedian;
+    }
+}

@@ -161,6 +161,10 @@ int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const
                                  const float *F12, float epx, float epy, int bOnlyStereo, int bCoarse,
                                  int checkOrientation, int *matches12Out);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:343-416) for a batch of descriptor sets */
+void orc_distinctive_descriptors(int nSets, const int *setOff, const uint8_t *desc, int *bestIdxOut,
+                                 int *bestMedianOut);
+
 /* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480): linear cell per kp or -1 */
 void orc_assign_grid(const orc_frame_view *F, int *cellOut);
 

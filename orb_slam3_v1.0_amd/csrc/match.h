@@ -47,6 +47,9 @@ int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* of
                             const uint8_t* stereo1, int n2, const orbfe_keypoint* kp2, const uint8_t* desc2,
                             const uint8_t* hasMP2, const uint8_t* stereo2, const float* sf2, int nLevels2,
                             const orbfe_tri_params* P, int* matches12, int* nMatches, std::string& err);
+// kernels_distinct.hip (MapPoint::ComputeDistinctiveDescriptors for a batch)
+int distinctive_run(MatchScratch& m, hipStream_t s, int nSets, const int* setOff, const uint8_t* desc, int* bestIdx,
+                    int* bestMedian, std::string& err);
 // kernels_frustum.hip
 int frustum_validate(const orbfe_frustum* F);
 int frustum_launch(hipStream_t s, const orbfe_frustum* F, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,

@@ -791,6 +791,20 @@ int orbfe_match_triangulation(orbfe_handle* h, int n_groups, const int* kf1_off,
     return rc;
 }
 
+int orbfe_distinctive_descriptors(orbfe_handle* h, int n_sets, const int* set_off, const uint8_t* desc, int* best_idx_out,
+                                  int* best_median_out)
+{
+    if (!h || n_sets < 0 || (n_sets > 0 && (!set_off || !best_idx_out || set_off[0] != 0)) ||
+        (n_sets > 0 && set_off[n_sets] > 0 && !desc))
+        return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = distinctive_run(h->match, h->stream, n_sets, set_off, desc, best_idx_out, best_median_out, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
 struct orbfe_vocab {
     orbfe::Vocab* v;
     int device;

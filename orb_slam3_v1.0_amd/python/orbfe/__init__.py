@@ -69,7 +69,7 @@ SYMBOLS = [
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
     "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
-    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_match_triangulation", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
@@ -132,6 +132,7 @@ def lib():
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
     L.orbfe_match_triangulation.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci,
                                             C.POINTER(TriParams), vp, vp]
+    L.orbfe_distinctive_descriptors.argtypes = [vp, ci, vp, vp, vp, vp]
     L.orbfe_vocab_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocab_destroy.argtypes = [vp]
     L.orbfe_vocab_destroy.restype = None
@@ -353,6 +354,18 @@ class ORBmatcher:
                                                      _p(s2), _p(sf), len(sf), C.byref(P), _p(out), C.byref(n)),
                     "orbfe_match_triangulation")
         return n.value, out[:len(kp1)].copy()
+
+    def ComputeDistinctiveDescriptors(self, setOff, desc):
+        """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:343-416) for a batch of descriptor sets (CSR):
+        returns (index of the representative inside each set, its median distance)."""
+        setOff = np.ascontiguousarray(setOff, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(setOff) - 1
+        bi = np.zeros(max(n, 1), np.int32)
+        bm = np.zeros(max(n, 1), np.int32)
+        self.e._chk(self.L.orbfe_distinctive_descriptors(self.e.h, n, _p(setOff), _p(desc), _p(bi), _p(bm)),
+                    "orbfe_distinctive_descriptors")
+        return bi[:n], bm[:n]
 
     def Fuse_search(self, kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
         """The search part of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:678-836): (bestIdx, bestDist)

@@ -90,6 +90,8 @@ def lib():
         L.orc_is_in_frustum.restype = None
         L.orc_fuse_search.argtypes = [C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
         L.orc_fuse_search.restype = None
+        L.orc_distinctive_descriptors.argtypes = [ci, vp, vp, vp, vp]
+        L.orc_distinctive_descriptors.restype = None
         L.orc_search_for_triangulation.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, cf,
                                                    ci, ci, ci, vp]
         _lib = L
@@ -328,3 +330,13 @@ def search_for_triangulation(off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1
 
 def spec_atan2f(y, x):
     return float(lib().orc_spec_atan2f(float(np.float32(y)), float(np.float32(x))))
+
+
+def distinctive_descriptors(setOff, desc):
+    setOff = np.ascontiguousarray(setOff, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(setOff) - 1
+    bi = np.zeros(max(n, 1), np.int32)
+    bm = np.zeros(max(n, 1), np.int32)
+    lib().orc_distinctive_descriptors(n, _p(setOff), _p(desc), _p(bi), _p(bm))
+    return bi[:n], bm[:n]
