@@ -495,14 +495,13 @@ static int check_device_flags(orbfe_handle* h, int batch)
     return ORBFE_OK;
 }
 
-// H2D of the staged frames, kernel chain, D2H of the result block (one copy for a full batch)
-static int extract_host_enqueue(orbfe_handle* h, int batch, hipStream_t s)
+// kernel chain on the frames already sent to dIn, D2H of the result block (one copy for a full batch)
+static int extract_host_enqueue(orbfe_handle* h, int batch, int inPitch, hipStream_t s)
 {
     const int nL = h->nLevels;
     const size_t inFrame = (size_t)h->dInPitch * h->prm.image_height;
     const size_t cap = (size_t)h->P.kpCapFrame;
-    HIPCHK(h, hipMemcpyAsync(h->dIn, h->hIn, inFrame * batch, hipMemcpyHostToDevice, s));
-    const int rc = extract_chain(h, h->dIn, inFrame, h->dInPitch, batch, h->dKp, h->dDesc, h->dN, h->dPer, h->dStatus, s);
+    const int rc = extract_chain(h, h->dIn, inFrame, inPitch, batch, h->dKp, h->dDesc, h->dN, h->dPer, h->dStatus, s);
     if (rc != ORBFE_OK) return rc;
     if (batch == h->maxBatch) {
         HIPCHK(h, hipMemcpyAsync(h->hOutBlock, h->dOutBlock, h->outBlockBytes, hipMemcpyDeviceToHost, s));
@@ -525,47 +524,72 @@ int orbfe_extract_batch(orbfe_handle* h, const uint8_t* const* grays, int pitch,
     HIPCHK(h, hipSetDevice(h->device));
     const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;
     const size_t inFrame = (size_t)h->dInPitch * H;
+    hipStream_t s = h->stream;
+    // Upload.  Pinned sources (the reference hands over cv::cuda::HostMem, include/ORBextractor.h:62) with a
+    // dword-aligned pitch that fits the device staging rows are copied by the DMA engine straight from the caller's
+    // buffer, keeping the caller's pitch (level 0 is read with an arbitrary pitch anyway); everything else is
+    // re-pitched through the handle's pinned staging block first.
+    bool direct = pitch <= h->dInPitch && (pitch & 3) == 0;
     for (int b = 0; b < batch; b++) {
         if (!grays[b]) return ORBFE_ERR_INVALID_ARG;
-        for (int y = 0; y < H; y++)
-            memcpy(h->hIn + b * inFrame + (size_t)y * h->dInPitch, grays[b] + (size_t)y * pitch, (size_t)W);
+        if (direct) {
+            hipPointerAttribute_t attr;
+            if ((reinterpret_cast<uintptr_t>(grays[b]) & 3u) != 0 || hipPointerGetAttributes(&attr, grays[b]) != hipSuccess ||
+                attr.type != hipMemoryTypeHost) {
+                (void)hipGetLastError();
+                direct = false;
+            }
+        }
     }
-    hipStream_t s = h->stream;
+    const int inPitch = direct ? pitch : h->dInPitch;
+    if (direct) {
+        const size_t bytes = (size_t)pitch * (H - 1) + (size_t)W;
+        for (int b = 0; b < batch; b++)
+            HIPCHK(h, hipMemcpyAsync(h->dIn + b * inFrame, grays[b], bytes, hipMemcpyHostToDevice, s));
+    } else {
+        for (int b = 0; b < batch; b++)
+            for (int y = 0; y < H; y++)
+                memcpy(h->hIn + b * inFrame + (size_t)y * h->dInPitch, grays[b] + (size_t)y * pitch, (size_t)W);
+        HIPCHK(h, hipMemcpyAsync(h->dIn, h->hIn, inFrame * batch, hipMemcpyHostToDevice, s));
+    }
     int rc;
-    if (h->useGraph && !h->timing) {
-        // every pointer of the call is owned by the handle, so the enqueue sequence is captured once per batch
-        // size and replayed with a single hipGraphLaunch (11 launches + 2..6 copies otherwise)
-        hipGraphExec_t& exec = h->graphs[batch];
+    bool viaGraph = h->useGraph && !h->timing && batch < 4096;
+    if (viaGraph) {
+        // every pointer behind the upload is owned by the handle, so the enqueue sequence (memset, 10 kernels, result
+        // copy) is captured once per batch size and replayed with a single hipGraphLaunch
+        const int gkey = batch | (inPitch << 12);  // batch <= 4095 frames per call in graph mode, else plain launches
+        hipGraphExec_t& exec = h->graphs[gkey];
         if (!exec) {
             hipGraph_t graph = nullptr;
             HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = extract_host_enqueue(h, batch, s);
+            rc = extract_host_enqueue(h, batch, inPitch, s);
             const hipError_t ec = hipStreamEndCapture(s, &graph);
             if (rc != ORBFE_OK || ec != hipSuccess || !graph) {
                 if (graph) (void)hipGraphDestroy(graph);
-                h->graphs.erase(batch);
+                h->graphs.erase(gkey);
                 h->useGraph = false;  // fall back to plain launches for the lifetime of the handle
                 (void)hipGetLastError();
             } else {
                 const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
                 if (ei != hipSuccess) {
-                    h->graphs.erase(batch);
+                    h->graphs.erase(gkey);
                     h->useGraph = false;
                     (void)hipGetLastError();
                 }
             }
         }
-        if (h->useGraph) {
-            HIPCHK(h, hipGraphLaunch(h->graphs[batch], s));
+        viaGraph = h->useGraph;  // capture may have failed: plain launches below
+        if (viaGraph) {
+            HIPCHK(h, hipGraphLaunch(h->graphs[gkey], s));
             h->lastGray = h->dIn;  // what extract_chain records on a plain launch (pyramid / candidate getters)
             h->lastStride = inFrame;
-            h->lastPitch = h->dInPitch;
+            h->lastPitch = inPitch;
             h->lastBatch = batch;
         }
     }
-    if (!h->useGraph || h->timing) {
-        rc = extract_host_enqueue(h, batch, s);
+    if (!viaGraph) {
+        rc = extract_host_enqueue(h, batch, inPitch, s);
         if (rc != ORBFE_OK) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(s));

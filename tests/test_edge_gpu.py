@@ -149,3 +149,36 @@ def test_graph_replay_equals_plain_launches(built):
         return np.array_equal(np.asarray(u), np.asarray(v))
 
     assert same(a, b) and same(a, c)
+
+
+@pytest.mark.gpu
+def test_pinned_input_fast_path(built):
+    """Pinned host images (what the reference passes: cv::cuda::HostMem) are uploaded straight from the caller's buffer
+    with a pitch-converting DMA copy; results must equal the pageable (staged) path, also for a padded pitch."""
+    import torch
+    import orbfe
+    from orbfe import synth
+    W, H = 320, 240
+    ex = orbfe.ORBextractor(600, 8000, 1.2, 6, 20, 7, W, H, device=0, max_batch=2)
+    img = synth.frame(W, H, 3)
+    ref = ex.extractFeatures(img)
+    pin = torch.empty((H, W + 40), dtype=torch.uint8).pin_memory()
+    pin[:, :W] = torch.from_numpy(img)
+    view = pin.numpy()[:, :W]  # pitch W + 40, pinned
+    got = ex.extractFeatures(view)
+    assert got[0].tobytes() == ref[0].tobytes() and np.array_equal(got[1], ref[1])
+    got2 = ex.extractFeatures(view)  # graph replay after the pinned upload
+    assert got2[0].tobytes() == ref[0].tobytes()
+    # a pinned image whose pitch fits the device rows is sent without re-pitching and read with the caller's pitch
+    ex2 = orbfe.ORBextractor(600, 8000, 1.2, 6, 20, 7, 300, H, device=0, max_batch=2)  # device pitch 320
+    img2 = synth.frame(300, H, 4)
+    ref2 = ex2.extractFeatures(img2)
+    for pitch in (300, 304, 320):
+        pin2 = torch.empty((H, pitch), dtype=torch.uint8).pin_memory()
+        pin2[:, :300] = torch.from_numpy(img2)
+        v2 = pin2.numpy()[:, :300]
+        for _ in range(2):  # capture, then replay
+            g = ex2.extractFeatures(v2)
+            assert g[0].tobytes() == ref2[0].tobytes() and np.array_equal(g[1], ref2[1]), pitch
+        b = ex2.extract_batch([v2, v2])
+        assert b[0][0].tobytes() == ref2[0].tobytes() and b[1][0].tobytes() == ref2[0].tobytes()
