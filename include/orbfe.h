@@ -301,6 +301,50 @@ int orbfe_fuse_search(orbfe_handle *h, const orbfe_frame_view *KF, const float *
                       const orbfe_world_point *points, const uint8_t *mp_desc, int *best_idx_out,
                       int *best_dist_out);
 
+/* replaces the search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:864-975;
+ * no caller in this fork -- the loop-closing thread is gone -- but part of the class, include/ORBmatcher.h:69): the
+ * same walk as orbfe_fuse_search without the chi-square gate.  The caller decomposes Scw as the reference does
+ * (:867-868): frustum->rcw = Scw.rotationMatrix(), tcw = Scw.translation() / Scw.scale(), twc =
+ * Tcw.inverse().translation(); points[i].skip carries "spAlreadyFound.count(pMP)".  The caller applies
+ * bestDist <= TH_LOW, vpReplacePoint and the graph edits (:955-971) in list order.  HOST pointers. */
+int orbfe_fuse_search_sim3(orbfe_handle *h, const orbfe_frame_view *KF, const orbfe_frustum *frustum, float th, int M,
+                           const orbfe_world_point *points, const uint8_t *mp_desc, int *best_idx_out,
+                           int *best_dist_out);
+
+/* one search direction of ORBmatcher::SearchBySim3 */
+typedef struct orbfe_sim3_view {
+    float rcw[9], tcw[3];     /* pose of the key frame that owns the map points (T1w for 1->2, :986-987) */
+    float sr[9], t[3];        /* the similarity into the other key frame as s*R (row-major) and t (S21 for 1->2) */
+    float fx, fy, cx, cy;     /* pKF1's intrinsics -- the reference uses them for both directions (:979-982) */
+    float min_x, max_x, min_y, max_y; /* mnMinX .. mnMaxY of the TARGET key frame (KeyFrame::IsInImage) */
+    float log_scale_factor;   /* mfLogScaleFactor of the target key frame */
+    int n_levels;             /* mnScaleLevels of the target key frame */
+} orbfe_sim3_view;
+
+/* replaces ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (src/ORBmatcher.cc:977-1200; no caller in this
+ * fork).  mp1 / mp_desc1: one record per feature of key frame 1 (KF1->n entries; skip = "no map point" or
+ * vbAlreadyMatched1 of :1001-1012), mp2 / mp_desc2 likewise for key frame 2.  dir12 moves key frame 1's points
+ * into key frame 2 (T1w, S21), dir21 the other way (T2w, S12).  match12_out[i1] (KF1->n ints) = feature of key
+ * frame 2 whose map point the reference stores in vpMatches12[i1], or -1; *n_found = the return value.
+ * HOST pointers. */
+int orbfe_search_by_sim3(orbfe_handle *h, const orbfe_frame_view *KF1, const orbfe_frame_view *KF2,
+                         const orbfe_sim3_view *dir12, const orbfe_sim3_view *dir21, const orbfe_world_point *mp1,
+                         const uint8_t *mp_desc1, const orbfe_world_point *mp2, const uint8_t *mp_desc2, float th,
+                         int *match12_out, int *n_found);
+
+/* replaces ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, checkOrientation)
+ * (src/ORBmatcher.cc:1202-1326, the relocalisation overload; no caller in this fork).  points / mp_desc / kf_angle:
+ * one record per feature i of the key frame (skip = "no map point" or "in sAlreadyFound"; kf_angle[i] =
+ * pKF->mvKeysUn[i].angle, may be NULL when check_orientation == 0); frustum = the current frame's pose, bounds,
+ * camera and scale pyramid; frame_has_mp[i2] != 0 iff CurrentFrame->mvpMapPoints[i2] is set on entry (NULL == none).
+ * match_out[i2] (frame->n ints) = key-frame feature whose map point this call leaves in
+ * CurrentFrame->mvpMapPoints[i2], or -1; *n_matches = the return value.  The greedy order-dependent claims and the
+ * rotation-histogram filter are reproduced exactly.  HOST pointers. */
+int orbfe_match_projection_keyframe(orbfe_handle *h, const orbfe_frame_view *frame, const orbfe_frustum *frustum,
+                                    int n_points, const orbfe_world_point *points, const uint8_t *mp_desc,
+                                    const float *kf_angle, const uint8_t *frame_has_mp, float th,
+                                    int check_orientation, int *match_out, int *n_matches);
+
 /* replaces the selection loop of MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:343-416; called after every
  * AddObservation / Fuse, src/LocalMapping.cc) for a batch of map points: set s holds the observed descriptors
  * desc[set_off[s] .. set_off[s+1]) (32 bytes each, in the order the reference collects them); best_idx_out[s] =

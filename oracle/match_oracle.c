@@ -509,9 +509,9 @@ void orc_is_in_frustum(const orc_frustum *F, int n, const orc_world_point *pts, 
  * pts[i].skip carries "!pMP || pMP->IsInKeyFrame(pKF)", pts[i].bad carries isBad() (:706-721).
  * uRight == NULL means a monocular key frame (mvuRight[i] < 0 for all i).
  * ------------------------------------------------------------------------------------------ */
-void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, const float *uRight, const orc_frustum *F,
-                     float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
-                     int *bestDistOut)
+static void fuse_search_body(const orc_frame_view *KF, const float *invLevelSigma2, const float *uRight,
+                             const orc_frustum *F, float th, int M, const orc_world_point *pts, const uint8_t *mpDesc,
+                             int chi2Gate, int *bestIdxOut, int *bestDistOut)
 {
     cell_t *g = build_grid(KF);
     int *vIndices = (int *)malloc(sizeof(int) * (size_t)(KF->n > 0 ? KF->n : 1));
@@ -551,7 +551,9 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
             const orc_keypoint *kp = &KF->kp[idx];
             const int kpLevel = kp->octave;
             if (kpLevel < lvl - 1 || kpLevel > lvl) continue; /* :787 */
-            if (uRight && uRight[idx] >= 0) {
+            if (!chi2Gate) {
+                /* the Sim3 overload has no reprojection gate (:937-953) */
+            } else if (uRight && uRight[idx] >= 0) {
                 const float ex = u - kp->x, ey = v - kp->y, er = ur - uRight[idx];
                 const float e2 = (ex * ex + ey * ey) + er * er;
                 if (e2 * invLevelSigma2[kpLevel] > 7.8) continue; /* float product against a double constant */
@@ -571,6 +573,205 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
     }
     free(vIndices);
     free_grid(KF, g);
+}
+
+void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, const float *uRight, const orc_frustum *F,
+                     float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
+                     int *bestDistOut)
+{
+    fuse_search_body(KF, invLevelSigma2, uRight, F, th, M, pts, mpDesc, 1, bestIdxOut, bestDistOut);
+}
+
+/* The search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:864-975):
+ * the same walk as above without the viewing-angle and chi-square tests.  The caller decomposes Scw as the
+ * reference does (:867-868): F->rcw = Scw.rotationMatrix(), F->tcw = Scw.translation() / Scw.scale(),
+ * F->twc = Tcw.inverse().translation(); pts[i].skip carries "spAlreadyFound.count(pMP)".  bestDist starts at
+ * INT_MAX in the reference; 256 here is equivalent (every distance is <= 256 and only "<= TH_LOW" is read). */
+void orc_fuse_search_sim3(const orc_frame_view *KF, const orc_frustum *F, float th, int M, const orc_world_point *pts,
+                          const uint8_t *mpDesc, int *bestIdxOut, int *bestDistOut)
+{
+    fuse_search_body(KF, NULL, NULL, F, th, M, pts, mpDesc, 0, bestIdxOut, bestDistOut);
+}
+
+/* PredictScale (src/MapPoint.cc:580-612), SPEC DECISION S8 */
+static int predict_scale(float maxDistance, float dist, float logScaleFactor, int nLevels)
+{
+    const float ratio = maxDistance / dist;
+    const float q = orc_spec_logf(ratio) / logScaleFactor;
+    int lvl;
+    if (!(q > 0.0f)) lvl = 0;
+    else if (q >= (float)nLevels) lvl = nLevels - 1;
+    else {
+        lvl = (int)ceilf(q);
+        if (lvl >= nLevels) lvl = nLevels - 1;
+    }
+    return lvl;
+}
+
+/* One direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1017-1092 for 1->2, :1094-1170 for 2->1): the map
+ * points of the source key frame are taken to its camera frame (D->rcw, D->tcw = source pose), moved by the
+ * similarity (D->sr = s*R, D->t), projected with the PINHOLE expression written out in the function itself
+ * (:1038-1043: invz = 1/z, u = fx * (x * invz) + cx -- not GeometricCamera::project, and with pKF1's intrinsics
+ * in both directions, :979-982) and searched in the target key frame.  SPEC DECISION S8 arithmetic. */
+static void sim3_direction(const orc_frame_view *T, const orc_sim3_dir *D, int n, const orc_world_point *pts,
+                           const uint8_t *mpDesc, float th, int *vnMatch)
+{
+    cell_t *g = build_grid(T);
+    int *vIndices = (int *)malloc(sizeof(int) * (size_t)(T->n > 0 ? T->n : 1));
+    for (int i = 0; i < n; i++) {
+        vnMatch[i] = -1;
+        const orc_world_point *p = &pts[i];
+        if (p->skip || p->bad) continue; /* !pMP || vbAlreadyMatched (:1021), isBad (:1024) */
+        const float X = p->x, Y = p->y, Z = p->z;
+        const float ax = ((D->rcw[0] * X + D->rcw[1] * Y) + D->rcw[2] * Z) + D->tcw[0]; /* p3Dc1 = T1w * p3Dw */
+        const float ay = ((D->rcw[3] * X + D->rcw[4] * Y) + D->rcw[5] * Z) + D->tcw[1];
+        const float az = ((D->rcw[6] * X + D->rcw[7] * Y) + D->rcw[8] * Z) + D->tcw[2];
+        const float bx = ((D->sr[0] * ax + D->sr[1] * ay) + D->sr[2] * az) + D->t[0]; /* p3Dc2 = S21 * p3Dc1 */
+        const float by = ((D->sr[3] * ax + D->sr[4] * ay) + D->sr[5] * az) + D->t[1];
+        const float bz = ((D->sr[6] * ax + D->sr[7] * ay) + D->sr[8] * az) + D->t[2];
+        if (bz < 0.0f) continue; /* :1032 */
+        const float invz = 1.0f / bz; /* 1.0 / z in double, rounded to float: identical to the float quotient */
+        const float x = bx * invz, y = by * invz;
+        const float u = D->fx * x + D->cx, v = D->fy * y + D->cy;
+        if (!(u >= D->minX && u < D->maxX && v >= D->minY && v < D->maxY)) continue; /* KeyFrame::IsInImage */
+        const float maxD = 1.1f * p->maxDistance, minD = 0.9f * p->minDistance;
+        const float dist3D = sqrtf((bx * bx + by * by) + bz * bz); /* p3Dc2.norm() */
+        if (dist3D < minD || dist3D > maxD) continue; /* :1052 */
+        const int lvl = predict_scale(p->maxDistance, dist3D, D->logScaleFactor, D->nLevels);
+        const float radius = th * T->scaleFactors[lvl]; /* :1060 */
+        const int nc = features_in_area(T, g, u, v, radius, -1, -1, vIndices);
+        int bestDist = 256 + 1, bestIdx = -1; /* INT_MAX in the reference: any candidate replaces it */
+        for (int c = 0; c < nc; c++) {
+            const int idx = vIndices[c];
+            const int oct = T->kp[idx].octave;
+            if (oct < lvl - 1 || oct > lvl) continue; /* :1078 */
+            const int dist = orc_hamming(mpDesc + (size_t)i * 32, T->desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx; /* :1088 */
+    }
+    free(vIndices);
+    free_grid(T, g);
+}
+
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:977-1200).  mp1 / mp2: one record per key-frame feature
+ * (KF->n entries; skip = "no map point" or vbAlreadyMatched of :1001-1012, which the caller derives from
+ * vpMatches12 and GetIndexInKeyFrame).  match12Out[i1] = index in key frame 2 whose map point the reference
+ * writes into vpMatches12[i1], or -1; returns nFound. */
+int orc_search_by_sim3(const orc_frame_view *KF1, const orc_frame_view *KF2, const orc_sim3_dir *d12,
+                       const orc_sim3_dir *d21, const orc_world_point *mp1, const uint8_t *mpDesc1,
+                       const orc_world_point *mp2, const uint8_t *mpDesc2, float th, int *match12Out)
+{
+    const int N1 = KF1->n, N2 = KF2->n;
+    int *vn1 = (int *)malloc(sizeof(int) * (size_t)(N1 > 0 ? N1 : 1));
+    int *vn2 = (int *)malloc(sizeof(int) * (size_t)(N2 > 0 ? N2 : 1));
+    sim3_direction(KF2, d12, N1, mp1, mpDesc1, th, vn1);
+    sim3_direction(KF1, d21, N2, mp2, mpDesc2, th, vn2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) { /* :1175-1189 */
+        match12Out[i1] = -1;
+        const int idx2 = vn1[i1];
+        if (idx2 >= 0 && vn2[idx2] == i1) {
+            match12Out[i1] = idx2;
+            nFound++;
+        }
+    }
+    free(vn1);
+    free(vn2);
+    return nFound;
+}
+
+/* ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, checkOrientation)
+ * (src/ORBmatcher.cc:1202-1326, relocalisation).  pts[i] / mpDesc / kfAngle: one record per key-frame feature i
+ * (skip = "no map point" or "in sAlreadyFound"); frameHasMP[i2] != 0 iff CurrentFrame->mvpMapPoints[i2] is set on
+ * entry (NULL == none).  matchOut[i2] = key-frame feature index whose map point ends up in
+ * CurrentFrame->mvpMapPoints[i2] through this call, or -1; returns nmatches.
+ * Note what the reference does NOT test here: the depth sign (a point behind the camera projects through the
+ * pinhole expression like any other) -- reproduced.  A NaN projection passes the bounds test (:1232-1235) and
+ * reaches Frame::GetFeaturesInArea, whose float-to-int conversion is then undefined; it yields an empty query on
+ * x86 (INT_MIN cell) -- the oracle makes that explicit. */
+int orc_search_by_projection_kf(const orc_frame_view *F, const orc_frustum *Fr, int M, const orc_world_point *pts,
+                                const uint8_t *mpDesc, const float *kfAngle, const uint8_t *frameHasMP, float th,
+                                int checkOrientation, int *matchOut)
+{
+    int nmatches = 0;
+    cell_t *g = build_grid(F);
+    const int nF = F->n;
+    int *vIndices = (int *)malloc(sizeof(int) * (size_t)(nF > 0 ? nF : 1));
+    uint8_t *taken = (uint8_t *)malloc((size_t)(nF > 0 ? nF : 1));
+    int *rotHist[HISTO_LENGTH];
+    int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(nF > 0 ? nF : 1));
+        rotN[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < nF; i++) {
+        matchOut[i] = -1;
+        taken[i] = frameHasMP ? (frameHasMP[i] != 0) : 0;
+    }
+    for (int i = 0; i < M; i++) {
+        const orc_world_point *p = &pts[i];
+        if (p->skip || p->bad) continue; /* :1221-1225 */
+        const float X = p->x, Y = p->y, Z = p->z;
+        const float pcx = ((Fr->rcw[0] * X + Fr->rcw[1] * Y) + Fr->rcw[2] * Z) + Fr->tcw[0];
+        const float pcy = ((Fr->rcw[3] * X + Fr->rcw[4] * Y) + Fr->rcw[5] * Z) + Fr->tcw[1];
+        const float pcz = ((Fr->rcw[6] * X + Fr->rcw[7] * Y) + Fr->rcw[8] * Z) + Fr->tcw[2];
+        float u, v;
+        camera_project(Fr, pcx, pcy, pcz, &u, &v); /* :1230 */
+        if (u < Fr->minX || u > Fr->maxX) continue;
+        if (v < Fr->minY || v > Fr->maxY) continue;
+        if (u != u || v != v) continue; /* see the header note */
+        const float ox = X - Fr->twc[0], oy = Y - Fr->twc[1], oz = Z - Fr->twc[2];
+        const float dist3D = sqrtf((ox * ox + oy * oy) + oz * oz);
+        const float maxD = 1.1f * p->maxDistance, minD = 0.9f * p->minDistance;
+        if (dist3D < minD || dist3D > maxD) continue; /* :1245 */
+        const int lvl = predict_scale(p->maxDistance, dist3D, Fr->logScaleFactor, Fr->nLevels);
+        const float radius = th * F->scaleFactors[lvl]; /* :1253 */
+        const int nc = features_in_area(F, g, u, v, radius, lvl - 1, lvl + 1, vIndices);
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = vIndices[c];
+            if (taken[i2]) continue; /* :1268 */
+            const int dist = orc_hamming(mpDesc + (size_t)i * 32, F->desc + (size_t)i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= TH_HIGH) { /* :1282 */
+            matchOut[bestIdx2] = i;
+            taken[bestIdx2] = 1;
+            nmatches++;
+            if (checkOrientation) {
+                float rot = kfAngle[i] - F->kp[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin][rotN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (checkOrientation) { /* :1304-1323 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) {
+                matchOut[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(taken);
+    free(vIndices);
+    free_grid(F, g);
+    return nmatches;
 }
 
 /* ---------------------------------------------------------------------------------------------

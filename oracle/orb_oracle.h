@@ -153,6 +153,28 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
                      float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
                      int *bestDistOut);
 
+/* the search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:864-975) */
+void orc_fuse_search_sim3(const orc_frame_view *KF, const orc_frustum *F, float th, int M, const orc_world_point *pts,
+                          const uint8_t *mpDesc, int *bestIdxOut, int *bestDistOut);
+
+/* one search direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:977-1200) */
+typedef struct {
+    float rcw[9], tcw[3]; /* pose of the key frame that owns the map points */
+    float sr[9], t[3];    /* similarity into the other key frame: s * R and t */
+    float fx, fy, cx, cy; /* pKF1's intrinsics, both directions (:979-982) */
+    float minX, maxX, minY, maxY; /* image bounds of the target key frame */
+    float logScaleFactor;
+    int nLevels;          /* of the target key frame */
+} orc_sim3_dir;
+int orc_search_by_sim3(const orc_frame_view *KF1, const orc_frame_view *KF2, const orc_sim3_dir *d12,
+                       const orc_sim3_dir *d21, const orc_world_point *mp1, const uint8_t *mpDesc1,
+                       const orc_world_point *mp2, const uint8_t *mpDesc2, float th, int *match12Out);
+
+/* ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, checkOrientation) (src/ORBmatcher.cc:1202-1326) */
+int orc_search_by_projection_kf(const orc_frame_view *F, const orc_frustum *Fr, int M, const orc_world_point *pts,
+                                const uint8_t *mpDesc, const float *kfAngle, const uint8_t *frameHasMP, float th,
+                                int checkOrientation, int *matchOut);
+
 /* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:441-676), pinhole, one camera per key frame */
 int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const int *off2, const int *idx2v, int n1,
                                  const orc_keypoint *kp1, const uint8_t *desc1, const uint8_t *hasMP1,

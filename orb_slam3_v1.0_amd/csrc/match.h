@@ -40,7 +40,16 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
 // the search part of ORBmatcher::Fuse (kernels_match_proj.hip)
 int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, const float* invLevelSigma2,
                     const float* uRight, const orbfe_frustum* F, float th, int M, const orbfe_world_point* pts,
-                    const uint8_t* mpDesc, int* bestIdxOut, int* bestDistOut, std::string& err);
+                    const uint8_t* mpDesc, int chi2Gate, int* bestIdxOut, int* bestDistOut, std::string& err);
+// ORBmatcher::SearchBySim3 and the relocalisation SearchByProjection overload (kernels_match_proj.hip)
+int search_by_sim3_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF1, const orbfe_frame_view* KF2,
+                       const orbfe_sim3_view* d12, const orbfe_sim3_view* d21, const orbfe_world_point* mp1,
+                       const uint8_t* mpDesc1, const orbfe_world_point* mp2, const uint8_t* mpDesc2, float th,
+                       int* match12Out, int* nFound, std::string& err);
+int match_projection_kf_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* F, const orbfe_frustum* Fr, int M,
+                            const orbfe_world_point* pts, const uint8_t* mpDesc, const float* kfAngle,
+                            const uint8_t* frameHasMP, float th, int checkOrientation, int* matchOut, int* nMatches,
+                            std::string& err);
 // kernels_match_tri.hip
 int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* off1, const int* idx1, const int* off2,
                             const int* idx2, int n1, const orbfe_keypoint* kp1, const uint8_t* desc1, const uint8_t* hasMP1,

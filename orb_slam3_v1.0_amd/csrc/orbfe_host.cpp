@@ -787,8 +787,70 @@ int orbfe_fuse_search(orbfe_handle* h, const orbfe_frame_view* KF, const float* 
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
-    const int rc = fuse_search_run(h->match, h->stream, KF, inv_level_sigma2, u_right, frustum, th, M, points, mp_desc,
+    const int rc = fuse_search_run(h->match, h->stream, KF, inv_level_sigma2, u_right, frustum, th, M, points, mp_desc, 1,
                                    best_idx_out, best_dist_out, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+static bool view_args_bad(const orbfe_frame_view* V)
+{
+    return !V || V->n < 0 || (V->n > 0 && (!V->kp || !V->desc || !V->scale_factors));
+}
+
+int orbfe_fuse_search_sim3(orbfe_handle* h, const orbfe_frame_view* KF, const orbfe_frustum* frustum, float th, int M,
+                           const orbfe_world_point* points, const uint8_t* mp_desc, int* best_idx_out, int* best_dist_out)
+{
+    if (!h || view_args_bad(KF) || M < 0 || (M > 0 && (!points || !mp_desc || !best_idx_out || !best_dist_out)))
+        return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = fuse_search_run(h->match, h->stream, KF, nullptr, nullptr, frustum, th, M, points, mp_desc, 0,
+                                   best_idx_out, best_dist_out, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+static bool sim3_view_bad(const orbfe_sim3_view* D)
+{
+    return !D || D->n_levels < 1 || !(D->log_scale_factor > 0.0f);
+}
+
+int orbfe_search_by_sim3(orbfe_handle* h, const orbfe_frame_view* KF1, const orbfe_frame_view* KF2,
+                         const orbfe_sim3_view* dir12, const orbfe_sim3_view* dir21, const orbfe_world_point* mp1,
+                         const uint8_t* mp_desc1, const orbfe_world_point* mp2, const uint8_t* mp_desc2, float th,
+                         int* match12_out, int* n_found)
+{
+    if (!h || view_args_bad(KF1) || view_args_bad(KF2) || sim3_view_bad(dir12) || sim3_view_bad(dir21) || !n_found ||
+        (KF1->n > 0 && (!mp1 || !mp_desc1 || !match12_out)) || (KF2->n > 0 && (!mp2 || !mp_desc2)))
+        return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = search_by_sim3_run(h->match, h->stream, KF1, KF2, dir12, dir21, mp1, mp_desc1, mp2, mp_desc2, th,
+                                      match12_out, n_found, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+int orbfe_match_projection_keyframe(orbfe_handle* h, const orbfe_frame_view* frame, const orbfe_frustum* frustum,
+                                    int n_points, const orbfe_world_point* points, const uint8_t* mp_desc,
+                                    const float* kf_angle, const uint8_t* frame_has_mp, float th, int check_orientation,
+                                    int* match_out, int* n_matches)
+{
+    if (!h || view_args_bad(frame) || n_points < 0 || !n_matches || (frame->n > 0 && !match_out) ||
+        (n_points > 0 && (!points || !mp_desc || (check_orientation && !kf_angle))))
+        return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = match_projection_kf_run(h->match, h->stream, frame, frustum, n_points, points, mp_desc, kf_angle,
+                                           frame_has_mp, th, check_orientation, match_out, n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
 }

@@ -49,6 +49,14 @@ class Frustum(C.Structure):
                 ("n_levels", C.c_int), ("camera_model", C.c_int)]
 
 
+class Sim3View(C.Structure):
+    """orbfe_sim3_view: one search direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:977-1200)."""
+    _fields_ = [("rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("sr", C.c_float * 9), ("t", C.c_float * 3),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("min_x", C.c_float),
+                ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("log_scale_factor", C.c_float),
+                ("n_levels", C.c_int)]
+
+
 class TriParams(C.Structure):
     """orbfe_tri_params: F12, epipole and the three flags of SearchForTriangulation."""
     _fields_ = [("f12", C.c_float * 9), ("ep_x", C.c_float), ("ep_y", C.c_float), ("only_stereo", C.c_int),
@@ -69,7 +77,7 @@ SYMBOLS = [
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
     "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
-    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
 _lib = None
@@ -130,6 +138,11 @@ def lib():
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
+    L.orbfe_fuse_search_sim3.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
+    L.orbfe_search_by_sim3.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Sim3View),
+                                       C.POINTER(Sim3View), vp, vp, vp, vp, cf, vp, C.POINTER(ci)]
+    L.orbfe_match_projection_keyframe.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Frustum), ci, vp, vp, vp, vp, cf,
+                                                  ci, vp, C.POINTER(ci)]
     L.orbfe_match_triangulation.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci,
                                             C.POINTER(TriParams), vp, vp]
     L.orbfe_distinctive_descriptors.argtypes = [vp, ci, vp, vp, vp, vp]
@@ -380,6 +393,46 @@ class ORBmatcher:
         self.e._chk(self.L.orbfe_fuse_search(self.e.h, C.byref(kf_view), _p(is2), _p(ur), C.byref(frustum), th, M,
                                              _p(points), _p(mpDesc), _p(bi), _p(bd)), "orbfe_fuse_search")
         return bi[:M], bd[:M]
+
+    def Fuse_search_sim3(self, kf_view, frustum, th, points, mpDesc):
+        """The search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:864-975)."""
+        points = np.ascontiguousarray(points, WP_DTYPE)
+        mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+        M = len(points)
+        bi = np.zeros(max(M, 1), np.int32)
+        bd = np.zeros(max(M, 1), np.int32)
+        self.e._chk(self.L.orbfe_fuse_search_sim3(self.e.h, C.byref(kf_view), C.byref(frustum), th, M, _p(points),
+                                                  _p(mpDesc), _p(bi), _p(bd)), "orbfe_fuse_search_sim3")
+        return bi[:M], bd[:M]
+
+    def SearchBySim3(self, kf1_view, kf2_view, dir12, dir21, mp1, mpDesc1, mp2, mpDesc2, th):
+        """include/ORBmatcher.h:63 -> (nFound, match12) with match12[i1] = feature of key frame 2 or -1."""
+        mp1 = np.ascontiguousarray(mp1, WP_DTYPE)
+        mp2 = np.ascontiguousarray(mp2, WP_DTYPE)
+        assert len(mp1) == kf1_view.n and len(mp2) == kf2_view.n
+        mpDesc1 = np.ascontiguousarray(mpDesc1, np.uint8)
+        mpDesc2 = np.ascontiguousarray(mpDesc2, np.uint8)
+        out = np.full(max(1, kf1_view.n), -1, np.int32)
+        n = C.c_int()
+        self.e._chk(self.L.orbfe_search_by_sim3(self.e.h, C.byref(kf1_view), C.byref(kf2_view), C.byref(dir12),
+                                                C.byref(dir21), _p(mp1), _p(mpDesc1), _p(mp2), _p(mpDesc2), th, _p(out),
+                                                C.byref(n)), "orbfe_search_by_sim3")
+        return n.value, out[:kf1_view.n]
+
+    def SearchByProjection_keyframe(self, fv, frustum, points, mpDesc, kfAngle, frameHasMP, th, checkOrientation=True):
+        """include/ORBmatcher.h:48 (relocalisation overload) -> (nmatches, match) with match[i2] = key-frame feature
+        whose map point lands in CurrentFrame->mvpMapPoints[i2], or -1."""
+        points = np.ascontiguousarray(points, WP_DTYPE)
+        mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+        ang = None if kfAngle is None else np.ascontiguousarray(kfAngle, np.float32)
+        has = None if frameHasMP is None else np.ascontiguousarray(frameHasMP, np.uint8)
+        out = np.full(max(1, fv.n), -1, np.int32)
+        n = C.c_int()
+        self.e._chk(self.L.orbfe_match_projection_keyframe(self.e.h, C.byref(fv), C.byref(frustum), len(points),
+                                                           _p(points), _p(mpDesc), _p(ang), _p(has), th,
+                                                           int(bool(checkOrientation)), _p(out), C.byref(n)),
+                    "orbfe_match_projection_keyframe")
+        return n.value, out[:fv.n]
 
     def isInFrustum_batch_device(self, frustum, n, d_points, d_out, d_proj_xr=None, stream=None):
         self.e._chk(self.L.orbfe_project_map_points_device(self.e.h, C.byref(frustum), n, d_points, d_out, d_proj_xr,

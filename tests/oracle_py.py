@@ -28,6 +28,13 @@ class Frustum(C.Structure):
                 ("nLevels", C.c_int), ("cameraModel", C.c_int)]
 
 
+class Sim3Dir(C.Structure):
+    _fields_ = [("rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("sr", C.c_float * 9), ("t", C.c_float * 3),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("minX", C.c_float),
+                ("maxX", C.c_float), ("minY", C.c_float), ("maxY", C.c_float), ("logScaleFactor", C.c_float),
+                ("nLevels", C.c_int)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int), ("kp", C.c_void_p), ("desc", C.c_void_p), ("gridCols", C.c_int),
                 ("gridRows", C.c_int), ("minX", C.c_float), ("minY", C.c_float),
@@ -90,6 +97,13 @@ def lib():
         L.orc_is_in_frustum.restype = None
         L.orc_fuse_search.argtypes = [C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
         L.orc_fuse_search.restype = None
+        L.orc_fuse_search_sim3.argtypes = [C.POINTER(FrameView), C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
+        L.orc_fuse_search_sim3.restype = None
+        L.orc_search_by_sim3.argtypes = [C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Sim3Dir),
+                                         C.POINTER(Sim3Dir), vp, vp, vp, vp, cf, vp]
+        L.orc_search_by_sim3.restype = ci
+        L.orc_search_by_projection_kf.argtypes = [C.POINTER(FrameView), C.POINTER(Frustum), ci, vp, vp, vp, vp, cf, ci, vp]
+        L.orc_search_by_projection_kf.restype = ci
         L.orc_distinctive_descriptors.argtypes = [ci, vp, vp, vp, vp]
         L.orc_distinctive_descriptors.restype = None
         L.orc_search_for_triangulation.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, cf,
@@ -309,6 +323,38 @@ def fuse_search(kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
     bd = np.zeros(max(M, 1), np.int32)
     lib().orc_fuse_search(C.byref(kf_view), _p(is2), _p(ur), C.byref(frustum), th, M, _p(points), _p(mpDesc), _p(bi), _p(bd))
     return bi[:M], bd[:M]
+
+
+def fuse_search_sim3(kf_view, frustum, th, points, mpDesc):
+    points = np.ascontiguousarray(points, WP_DTYPE)
+    mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+    M = len(points)
+    bi = np.zeros(max(M, 1), np.int32)
+    bd = np.zeros(max(M, 1), np.int32)
+    lib().orc_fuse_search_sim3(C.byref(kf_view), C.byref(frustum), th, M, _p(points), _p(mpDesc), _p(bi), _p(bd))
+    return bi[:M], bd[:M]
+
+
+def search_by_sim3(kf1_view, kf2_view, d12, d21, mp1, mpDesc1, mp2, mpDesc2, th):
+    mp1 = np.ascontiguousarray(mp1, WP_DTYPE)
+    mp2 = np.ascontiguousarray(mp2, WP_DTYPE)
+    mpDesc1 = np.ascontiguousarray(mpDesc1, np.uint8)
+    mpDesc2 = np.ascontiguousarray(mpDesc2, np.uint8)
+    out = np.full(max(1, kf1_view.n), -1, np.int32)
+    n = lib().orc_search_by_sim3(C.byref(kf1_view), C.byref(kf2_view), C.byref(d12), C.byref(d21), _p(mp1), _p(mpDesc1),
+                                 _p(mp2), _p(mpDesc2), th, _p(out))
+    return n, out[:kf1_view.n]
+
+
+def search_by_projection_kf(fv, frustum, points, mpDesc, kfAngle, frameHasMP, th, checkOrientation=True):
+    points = np.ascontiguousarray(points, WP_DTYPE)
+    mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+    ang = None if kfAngle is None else np.ascontiguousarray(kfAngle, np.float32)
+    has = None if frameHasMP is None else np.ascontiguousarray(frameHasMP, np.uint8)
+    out = np.full(max(1, fv.n), -1, np.int32)
+    n = lib().orc_search_by_projection_kf(C.byref(fv), C.byref(frustum), len(points), _p(points), _p(mpDesc), _p(ang),
+                                          _p(has), th, int(bool(checkOrientation)), _p(out))
+    return n, out[:fv.n]
 
 
 def search_for_triangulation(off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1, kp2, desc2, hasMP2, stereo2,

@@ -42,7 +42,7 @@ def scenario(kp, desc, sf, v, M, seed, stereo):
     return pts, mpd, u_right, inv_sigma2
 
 
-def py_fuse_one(kp, desc, sf, inv_s2, u_right, v, th, p, d, grid=(64, 48)):
+def py_fuse_one(kp, desc, sf, inv_s2, u_right, v, th, p, d, grid=(64, 48), chi2=True):
     """Plain restatement of :722-826 for one map point on top of the pinned isInFrustum arithmetic; candidates are
     visited in GetFeaturesInArea order (cell x, cell y, index) with the strict '<' of :819."""
     f32 = np.float32
@@ -83,7 +83,7 @@ def py_fuse_one(kp, desc, sf, inv_s2, u_right, v, th, p, d, grid=(64, 48)):
         ex, ey = f32(u - k["x"]), f32(w - k["y"])
         assert u_right is None  # the stereo gate (:792-805) is covered by the GPU == oracle comparison
         e2 = f32(f32(ex * ex) + f32(ey * ey))
-        if float(f32(e2 * inv_s2[k["octave"]])) > 5.99:
+        if chi2 and float(f32(e2 * inv_s2[k["octave"]])) > 5.99:  # the Sim3 overload (:864-975) has no gate
             continue
         dist = int(np.unpackbits(desc[i] ^ d).sum())
         if dist < best:
