@@ -351,6 +351,125 @@ struct KeyFrameMatcher {
         }
         return nFused;
     }
+
+    // src/ORBmatcher.cc:864-975: Fuse(pKF, Scw, vpPoints, th, vpReplacePoint).  `frustum` carries the decomposition
+    // the reference makes at :867-868 (rcw = Scw.rotationMatrix(), tcw = Scw.translation() / Scw.scale(), twc =
+    // Tcw.inverse().translation()) plus the key frame's camera, bounds and scale pyramid.  spAlreadyFound is taken
+    // once on entry like the reference (:871); the replay loop applies :955-971 in list order on the live graph.
+    template <class KeyFramePtr, class MapPointPtr, class DescOfMP>
+    static int Fuse(orbfe_handle* h, KeyFramePtr pKF, const orbfe_frustum& frustum, const std::vector<MapPointPtr>& vpPoints,
+                    float th, std::vector<MapPointPtr>& vpReplacePoint, const orbfe_frame_view& kfView, DescOfMP descOfMP)
+    {
+        const int M = (int)vpPoints.size();
+        const auto spAlreadyFound = pKF->GetMapPoints();
+        std::vector<orbfe_world_point> pts(M > 0 ? M : 1);
+        std::vector<uint8_t> mpd((size_t)(M > 0 ? M : 1) * 32);
+        for (int i = 0; i < M; i++) {
+            const auto& pMP = vpPoints[i];
+            const auto P = pMP->GetWorldPos();
+            pts[i] = orbfe_world_point{P[0], P[1], P[2], pMP->mfMinDistance, pMP->mfMaxDistance, pMP->isBad() ? 1 : 0,
+                                       pMP->Observations(), spAlreadyFound.count(pMP) ? 1 : 0};
+            std::memcpy(&mpd[(size_t)i * 32], descOfMP(pMP), 32);
+        }
+        std::vector<int> bestIdx(M > 0 ? M : 1), bestDist(M > 0 ? M : 1);
+        orbfe_detail::check(orbfe_fuse_search_sim3(h, &kfView, &frustum, th, M, pts.data(), mpd.data(), bestIdx.data(),
+                                                   bestDist.data()), h, "orbfe_fuse_search_sim3");
+        int nFused = 0;
+        for (int i = 0; i < M; i++) {
+            const auto& pMP = vpPoints[i];
+            if (pts[i].bad || pts[i].skip) continue;       // :882 (nothing in this loop changes isBad of a later point)
+            if (bestDist[i] > ORBFE_TH_LOW) continue;       // :955
+            auto pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF, bestIdx[i]);
+                pKF->AddMapPoint(pMP, bestIdx[i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    // src/ORBmatcher.cc:977-1200.  dir12 / dir21 carry the poses and the similarity (T1w + S21, T2w + S12), pKF1's
+    // intrinsics and the target key frame's bounds / pyramid; `KF` needs GetMapPointMatches() and the map points
+    // GetIndexInKeyFrame(pKF) (a tuple whose first element is the left index, as in the reference, :1007).
+    template <class KeyFramePtr, class MapPointPtr, class DescOfMP>
+    static int SearchBySim3(orbfe_handle* h, KeyFramePtr pKF1, KeyFramePtr pKF2, std::vector<MapPointPtr>& vpMatches12,
+                            const orbfe_sim3_view& dir12, const orbfe_sim3_view& dir21, const float th,
+                            const orbfe_frame_view& view1, const orbfe_frame_view& view2, DescOfMP descOfMP)
+    {
+        const auto vpMapPoints1 = pKF1->GetMapPointMatches();
+        const auto vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+        std::vector<uint8_t> already1(N1 > 0 ? N1 : 1, 0), already2(N2 > 0 ? N2 : 1, 0);
+        for (int i = 0; i < N1; i++) {  // :1001-1012
+            const auto& pMP = vpMatches12[i];
+            if (!pMP) continue;
+            already1[i] = 1;
+            const int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+            if (idx2 >= 0 && idx2 < N2) already2[idx2] = 1;
+        }
+        auto pack = [&](const std::vector<MapPointPtr>& v, const std::vector<uint8_t>& already, std::vector<orbfe_world_point>& pts,
+                        std::vector<uint8_t>& d) {
+            const int n = (int)v.size();
+            pts.assign(n > 0 ? n : 1, orbfe_world_point{0, 0, 0, 0, 0, 0, 0, 1});
+            d.assign((size_t)(n > 0 ? n : 1) * 32, 0);
+            for (int i = 0; i < n; i++) {
+                const auto& pMP = v[i];
+                if (!pMP || already[i]) continue;
+                const auto P = pMP->GetWorldPos();
+                pts[i] = orbfe_world_point{P[0], P[1], P[2], pMP->mfMinDistance, pMP->mfMaxDistance, pMP->isBad() ? 1 : 0,
+                                           pMP->Observations(), 0};
+                std::memcpy(&d[(size_t)i * 32], descOfMP(pMP), 32);
+            }
+        };
+        std::vector<orbfe_world_point> p1, p2;
+        std::vector<uint8_t> d1, d2;
+        pack(vpMapPoints1, already1, p1, d1);
+        pack(vpMapPoints2, already2, p2, d2);
+        std::vector<int> m12(N1 > 0 ? N1 : 1, -1);
+        int nFound = 0;
+        orbfe_detail::check(orbfe_search_by_sim3(h, &view1, &view2, &dir12, &dir21, p1.data(), d1.data(), p2.data(), d2.data(),
+                                                 th, m12.data(), &nFound), h, "orbfe_search_by_sim3");
+        for (int i1 = 0; i1 < N1; i1++)
+            if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];  // :1184
+        return nFound;
+    }
+
+    // src/ORBmatcher.cc:1202-1326: the relocalisation overload SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th,
+    // checkOrientation).  `frustum` = the current frame's pose (GetPose / Tcw.inverse().translation()), bounds, camera
+    // and pyramid; `frameView` its keypoints, descriptors and grid.
+    template <class FramePtr, class KeyFramePtr, class MapPointSet, class DescOfMP>
+    static int SearchByProjection(orbfe_handle* h, FramePtr CurrentFrame, KeyFramePtr pKF, const MapPointSet& sAlreadyFound,
+                                  const float th, const bool checkOrientation, const orbfe_frustum& frustum,
+                                  const orbfe_frame_view& frameView, DescOfMP descOfMP)
+    {
+        const auto vpMPs = pKF->GetMapPointMatches();
+        const int M = (int)vpMPs.size(), n = frameView.n;
+        std::vector<orbfe_world_point> pts(M > 0 ? M : 1, orbfe_world_point{0, 0, 0, 0, 0, 0, 0, 1});
+        std::vector<uint8_t> mpd((size_t)(M > 0 ? M : 1) * 32);
+        std::vector<float> ang(M > 0 ? M : 1);
+        for (int i = 0; i < M; i++) {
+            ang[i] = (*pKF->mvKeysUn)[i].angle;
+            const auto& pMP = vpMPs[i];
+            if (!pMP) continue;
+            const auto P = pMP->GetWorldPos();
+            pts[i] = orbfe_world_point{P[0], P[1], P[2], pMP->mfMinDistance, pMP->mfMaxDistance, pMP->isBad() ? 1 : 0,
+                                       pMP->Observations(), sAlreadyFound.count(pMP) ? 1 : 0};
+            std::memcpy(&mpd[(size_t)i * 32], descOfMP(pMP), 32);
+        }
+        std::vector<uint8_t> has(n > 0 ? n : 1);
+        for (int i = 0; i < n; i++) has[i] = CurrentFrame->mvpMapPoints[i] ? 1 : 0;
+        std::vector<int> match(n > 0 ? n : 1, -1);
+        int nmatches = 0;
+        orbfe_detail::check(orbfe_match_projection_keyframe(h, &frameView, &frustum, M, pts.data(), mpd.data(), ang.data(),
+                                                            has.data(), th, checkOrientation ? 1 : 0, match.data(), &nmatches),
+                            h, "orbfe_match_projection_keyframe");
+        for (int i = 0; i < n; i++)
+            if (match[i] >= 0) CurrentFrame->mvpMapPoints[i] = vpMPs[match[i]];  // :1284 (entries the histogram removed stay as they were: empty)
+        return nmatches;
+    }
 };
 
 // The isInFrustum loop of Tracking::SearchLocalPoints (src/Tracking.cc:1059-1077) for all local map points in one

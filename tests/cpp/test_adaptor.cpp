@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <set>
+#include <tuple>
 
 #include "orbfe_adaptor.hpp"
 
@@ -42,6 +44,7 @@ struct MapPoint3D {  // the MapPoint members ORBmatcher::Fuse touches
     }
     void AddObservation(const std::shared_ptr<KeyFrame>& kf, size_t) { inKF.push_back(kf.get()); obs++; }
     void Replace(const std::shared_ptr<MapPoint3D>& other) { bad = true; other->obs += obs; }
+    std::tuple<int, int> GetIndexInKeyFrame(const std::shared_ptr<KeyFrame>&) const { return {-1, -1}; }
 };
 
 struct KeyFrame {
@@ -53,6 +56,17 @@ struct KeyFrame {
     std::vector<float> mvuRight, mvScaleFactors, mvInvLevelSigma2;
     std::shared_ptr<MapPoint3D> GetMapPoint(size_t i) const { return mvpMapPoints[i]; }
     void AddMapPoint(const std::shared_ptr<MapPoint3D>& mp, size_t i) { mvpMapPoints[i] = mp; }
+    std::vector<std::shared_ptr<MapPoint3D>> GetMapPointMatches() const { return mvpMapPoints; }
+    std::set<std::shared_ptr<MapPoint3D>> GetMapPoints() const
+    {
+        std::set<std::shared_ptr<MapPoint3D>> s;
+        for (auto& m : mvpMapPoints) if (m && !m->bad) s.insert(m);
+        return s;
+    }
+};
+
+struct RelocFrame {  // the Frame members the relocalisation overload writes
+    std::vector<std::shared_ptr<MapPoint3D>> mvpMapPoints;
 };
 
 struct Frame {
@@ -200,6 +214,57 @@ int main(int argc, char** argv)
         const int nf = KeyFrameMatcher::Fuse(ex.handle(), kf, mpts, 3.0f, fr, kv, 0,
                                              [](const std::shared_ptr<MapPoint3D>& m) { return m->desc; });
         std::printf("triangulation n=%d self=%zu fuse=%d of %zu\n", nt, self, nf, mpts.size());
+
+        // the remaining ORBmatcher statics on a key frame observed from its own pose (identity Sim3):
+        // every 3rd keypoint owns a map point sitting exactly on it
+        auto kf2 = std::make_shared<KeyFrame>(*kf);
+        kf2->mvpMapPoints.assign(n, nullptr);
+        kf->mvpMapPoints.assign(n, nullptr);
+        auto on_keypoint = [&](int i) {
+            auto mp = std::make_shared<MapPoint3D>();
+            const float z = 4.0f;
+            mp->wp[0] = ((*keys)[i].pt.x - fr.cx) / fr.fx * z;
+            mp->wp[1] = ((*keys)[i].pt.y - fr.cy) / fr.fy * z;
+            mp->wp[2] = z;
+            mp->mfMaxDistance = 5.0f * std::pow(1.2f, (float)(*keys)[i].octave);
+            mp->mfMinDistance = 0.05f;
+            std::memcpy(mp->desc, &desc[(size_t)i * 32], 32);
+            return mp;
+        };
+        for (int i = 0; i < n; i += 3) {
+            kf->mvpMapPoints[i] = on_keypoint(i);
+            kf2->mvpMapPoints[i] = on_keypoint(i);
+        }
+        auto descOfMP = [](const std::shared_ptr<MapPoint3D>& m) { return m->desc; };
+        orbfe_sim3_view dv{};
+        dv.rcw[0] = dv.rcw[4] = dv.rcw[8] = 1.0f;
+        dv.sr[0] = dv.sr[4] = dv.sr[8] = 1.0f;
+        dv.fx = fr.fx; dv.fy = fr.fy; dv.cx = fr.cx; dv.cy = fr.cy;
+        dv.min_x = 0.f; dv.max_x = (float)W; dv.min_y = 0.f; dv.max_y = (float)H;
+        dv.log_scale_factor = fr.log_scale_factor; dv.n_levels = ex.GetLevels();
+        std::vector<std::shared_ptr<MapPoint3D>> vpMatches12(n, nullptr);
+        const int nSim3 = KeyFrameMatcher::SearchBySim3(ex.handle(), kf, kf2, vpMatches12, dv, dv, 7.5f, kv, kv, descOfMP);
+        int sameSlot = 0;
+        for (int i = 0; i < n; i++) sameSlot += vpMatches12[i] && vpMatches12[i] == kf2->mvpMapPoints[i];
+        // Sim3 Fuse: candidates = key frame 2's points; key frame 1 holds points on the same keypoints -> replacements
+        std::vector<std::shared_ptr<MapPoint3D>> cand, vpReplace;
+        for (int i = 0; i < n; i += 3) cand.push_back(kf2->mvpMapPoints[i]);
+        for (int i = 1; i < n; i += 6) cand.push_back(on_keypoint(i));  // free keypoints -> new observations
+        vpReplace.assign(cand.size(), nullptr);
+        const int nFuse3 = KeyFrameMatcher::Fuse(ex.handle(), kf, fr, cand, 4.0f, vpReplace, kv, descOfMP);
+        int nRepl = 0, nAdded = 0;
+        for (auto& r : vpReplace) nRepl += r != nullptr;
+        for (int i = 1; i < n; i += 3) nAdded += kf->mvpMapPoints[i] != nullptr;
+        // relocalisation overload: key frame 2's points into an empty frame with the same keypoints
+        auto rf = std::make_shared<RelocFrame>();
+        rf->mvpMapPoints.assign(n, nullptr);
+        std::set<std::shared_ptr<MapPoint3D>> sFound;
+        sFound.insert(kf2->mvpMapPoints[0]);
+        const int nReloc = KeyFrameMatcher::SearchByProjection(ex.handle(), rf, kf2, sFound, 10.0f, true, fr, kv, descOfMP);
+        int relocSame = 0;
+        for (int i = 0; i < n; i++) relocSame += rf->mvpMapPoints[i] && rf->mvpMapPoints[i] == kf2->mvpMapPoints[i];
+        std::printf("sim3 found=%d same=%d fuse3=%d repl=%d added=%d reloc=%d same=%d slot0=%d\n", nSim3, sameSlot, nFuse3, nRepl,
+                    nAdded, nReloc, relocSame, rf->mvpMapPoints[0] ? 1 : 0);
     }
     std::printf("adaptor ok: %d keypoints, %d matches, levels=%d scale=%g\n", n, nm, ex.GetLevels(), ex.GetScaleFactor());
     return 0;

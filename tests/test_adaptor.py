@@ -92,3 +92,11 @@ def test_adaptor_matches_oracle(built, tmp_path):
     mt = re.search(r"triangulation n=(\d+) self=(\d+) fuse=(\d+) of (\d+)", stdout)
     assert mt and int(mt.group(1)) == nt and int(mt.group(2)) == int((m12 == np.arange(n_kp)).sum())
     assert int(mt.group(3)) > int(mt.group(4)) // 2  # most on-keypoint map points fuse
+    # SearchBySim3 / Sim3 Fuse / relocalisation SearchByProjection on a key frame seen from its own pose
+    ms = re.search(r"sim3 found=(\d+) same=(\d+) fuse3=(\d+) repl=(\d+) added=(\d+) reloc=(\d+) same=(\d+) slot0=(\d+)", stdout)
+    assert ms
+    found, same, fuse3, repl, added, reloc, rsame, slot0 = (int(g) for g in ms.groups())
+    n_mp = (n_kp + 2) // 3
+    assert found == same and found > n_mp * 0.8       # mutual best matches land on the construction's pairs
+    assert fuse3 == repl + added and repl > n_mp * 0.8 and added > 0
+    assert reloc == rsame and reloc > n_mp * 0.6 and slot0 == 0  # the point in sAlreadyFound is not searched
