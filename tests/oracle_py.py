@@ -56,7 +56,9 @@ def lib():
     if _lib is None:
         path = os.path.join(ODIR, "liborb_oracle.so")
         srcs = ("orb_oracle.c", "match_oracle.c", "orb_oracle.h")
-        if not os.path.exists(path) or any(
+        if os.environ.get("ORB_ORACLE_ASAN"):  # tests/test_oracle_asan.py: the sanitizer build of the same sources
+            path = build(asan=True)
+        elif not os.path.exists(path) or any(
                 os.path.getmtime(os.path.join(ODIR, f)) > os.path.getmtime(path) for f in srcs):
             build()
         L = C.CDLL(path)

@@ -46,3 +46,21 @@ def test_oracle_clean_under_asan_ubsan(tmp_path):
     script.write_text(DRIVER % {"root": ROOT})
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "asan-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_matcher_oracle_clean_under_asan_ubsan():
+    """The matcher half of the oracle (grid queries, projections, Sim3 / relocalisation searches, vocabulary descent)
+    under the sanitizers: the CPU parity tests of those files run once more against the instrumented build."""
+    try:
+        libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("gcc not available")
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not installed")
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               ORB_ORACLE_ASAN="1")
+    files = ["test_match_oracle.py", "test_match_init.py", "test_fuse.py", "test_sim3_reloc.py", "test_triangulation.py",
+             "test_frustum.py", "test_distinct.py", "test_vocab.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] +
+                       [os.path.join(ROOT, "tests", f) for f in files], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
