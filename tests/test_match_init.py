@@ -140,3 +140,33 @@ def test_init_hip_equals_oracle(built, window, nn, orient, grid):
     n_s, m_s = orbfe.ORBmatcher(ex).SearchForInitialization(g1, g1, window, nn, orient)
     n_so, m_so = O.search_for_initialization(f1, f1, window, nn, orient)
     assert n_s == n_so and np.array_equal(m_s, m_so)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels,nfeat,window,nn", [(1, 1000, 100, 0.9), (1, 2000, 60, 0.9), (2, 1500, 400, 0.95), (8, 1000, 1000, 0.9)])
+def test_init_fast_and_sequential_kernels_agree(built, monkeypatch, levels, nfeat, window, nn):
+    """Both device paths of orbfe_match_initialization against the oracle: the two-phase kernel (candidate keys in
+    parallel, one wave for the order-dependent part) and the sequential block kernel it replaces for large inputs.
+    One pyramid level puts every keypoint on level 0 (long candidate rows, rows that overflow the LDS image with a
+    huge window, > 1024 level-0 keypoints -> the sequential kernel is selected by the host)."""
+    import orbfe
+    W, H = 752, 480
+    args = (nfeat, 40000, 1.2, levels, 20, 7, W, H)
+    e = O.Extractor(*args)
+    fr = list(synth.stream(W, H, 2, index0=4))
+    kp1, d1, _ = e.extract(fr[0])
+    kp2, d2, _ = e.extract(fr[1])
+    f1 = O.make_frame_view(kp1, d1, 64, 48, 0.0, 0.0, float(W), float(H), e.scaleFactors)
+    f2 = O.make_frame_view(kp2, d2, 64, 48, 0.0, 0.0, float(W), float(H), e.scaleFactors)
+    n_ref, m_ref = O.search_for_initialization(f1, f2, window, nn, True)
+    assert n_ref > 20
+    ex = orbfe.ORBextractor(*args, device=0, max_batch=1)
+    g1 = orbfe.make_frame_view(kp1, d1, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    g2 = orbfe.make_frame_view(kp2, d2, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    for slow in ("", "1"):
+        if slow:
+            monkeypatch.setenv("ORBFE_INIT_SLOW", "1")
+        else:
+            monkeypatch.delenv("ORBFE_INIT_SLOW", raising=False)
+        n, m = orbfe.ORBmatcher(ex).SearchForInitialization(g1, g2, window, nn, True)
+        assert n == n_ref and np.array_equal(m, m_ref), slow

@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Per-call wall time of every matcher entry point of the C ABI (host pointers in and out: pinned staging, one
+H2D, the kernels, one D2H, stream sync) next to the single-thread C oracle on the same inputs, at the sizes of
+BASELINE config 1 (752x480, ~1000 keypoints).  Results are checked equal before timing.  DESIGN.md section 6
+quotes this table; it is never the bench's `value`.
+
+usage: python3 tools/matcher_latency.py [--reps 200] [--json out.json]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "orb_slam3_v1.0_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import frustum_scenarios as FS  # noqa: E402
+import match_scenarios as S  # noqa: E402
+import oracle_py as O  # noqa: E402
+import orbfe  # noqa: E402
+import test_distinct  # noqa: E402
+import test_fuse  # noqa: E402
+import test_sim3_reloc as T3  # noqa: E402
+import test_triangulation  # noqa: E402
+import vocab_synth as vs  # noqa: E402
+from orbfe import synth  # noqa: E402
+from test_frustum import ON, OP, PN  # noqa: E402
+
+W, H = 752, 480
+ARGS = (1000, 40000, 1.2, 8, 20, 7, W, H)
+MP_NAMES_O = ("projX", "projY", "viewCos", "trackDepth", "level", "inView", "bad", "observations")
+
+
+def timed(fn, reps):
+    fn()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t) / reps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    eo = O.Extractor(*ARGS)
+    ex = orbfe.ORBextractor(*ARGS)
+    m = orbfe.ORBmatcher(ex)
+    frames = list(synth.stream(W, H, 2))
+    kp, desc, _ = eo.extract(frames[0])
+    kpb, descb, _ = eo.extract(frames[1])
+    n = len(kp)
+    kpp, kpbp = kp.view(orbfe.KP_DTYPE), kpb.view(orbfe.KP_DTYPE)
+    sf = eo.scaleFactors
+    fvo = O.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, float(W), float(H), sf)
+    fv = orbfe.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    fvbo = O.make_frame_view(kpb, descb, 64, 48, 0.0, 0.0, float(W), float(H), sf)
+    fvb = orbfe.make_frame_view(kpb, descb, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    rows = []
+
+    def row(name, ref, size, gpu_fn, cpu_fn, same):
+        g, c = gpu_fn(), cpu_fn()
+        assert same(g, c), name
+        tg, tc = timed(gpu_fn, a.reps), timed(cpu_fn, a.cpu_reps)
+        rows.append(dict(entry=name, reference=ref, size=size, gpu_ms_per_call=tg, oracle_ms_per_call=tc, ratio=tc / tg))
+        print("%-36s %-44s gpu %7.3f ms   oracle(1 thread) %8.3f ms   x%.1f" % (name, size, tg, tc, tc / tg), flush=True)
+
+    eq2 = lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])
+    eqp = lambda g, c: np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1])
+
+    # a13
+    M = 2000
+    mps, mpd, init_obs = S.projection_scenario(kp, desc, M, 1, O.MP_DTYPE, MP_NAMES_O, 8)
+    row("orbfe_match_projection", "ORBmatcher.cc:31-123", "N=%d M=%d th=20" % (n, M),
+        lambda: m.SearchByProjection(fv, mps.view(orbfe.MP_DTYPE), mpd, 20.0, False, 0.0, 0.85, init_obs),
+        lambda: O.search_by_projection(fvo, mps, mpd, init_obs, 20.0, 0.85), eq2)
+    # a14
+    kf_off, kf_idx, f_off, f_idx, has = S.bow_scenario(kp, desc, kpb, descb, 100, 3)
+    row("orbfe_match_bow", "ORBmatcher.cc:133-327", "N=%d/%d nodes=%d" % (n, len(kpb), len(kf_off) - 1),
+        lambda: m.SearchByBoW(kf_off, kf_idx, f_off, f_idx, desc, kp["angle"], has, descb, kpb["angle"], 0.75, True),
+        lambda: O.search_by_bow(kf_off, kf_idx, f_off, f_idx, desc, kp["angle"], has, descb, kpb["angle"], 0.75, True), eq2)
+    # f1
+    row("orbfe_match_initialization", "ORBmatcher.cc:329-439", "N=%d/%d window=100" % (n, len(kpb)),
+        lambda: m.SearchForInitialization(fv, fvb, 100, 0.9, True),
+        lambda: O.search_for_initialization(fvo, fvbo, 100, 0.9, True), eq2)
+    # f3
+    Fo, Fp = O.Frustum(), orbfe.Frustum()
+    v = FS.fill_frustum(Fo, ON, seed=3)
+    FS.fill_frustum(Fp, PN, seed=3)
+    cloud = FS.world_points(4000, O.WP_DTYPE, OP, seed=5)
+    row("orbfe_project_map_points", "Frame.cc:272-331", "M=4000",
+        lambda: m.isInFrustum_batch(Fp, cloud.view(orbfe.WP_DTYPE)),
+        lambda: O.is_in_frustum(Fo, cloud),
+        lambda g, c: g[0].tobytes() == c[0].tobytes() and np.array_equal(g[1], c[1]))
+    # f2
+    pts, fmpd, _, inv_s2 = test_fuse.scenario(kp, desc, sf, v, M, 1, False)
+    row("orbfe_fuse_search", "ORBmatcher.cc:678-836", "N=%d M=%d th=3" % (n, M),
+        lambda: m.Fuse_search(fv, inv_s2, None, Fp, 3.0, pts.view(orbfe.WP_DTYPE), fmpd),
+        lambda: O.fuse_search(fvo, inv_s2, None, Fo, 3.0, pts, fmpd), eqp)
+    row("orbfe_fuse_search_sim3", "ORBmatcher.cc:864-975", "N=%d M=%d th=4" % (n, M),
+        lambda: m.Fuse_search_sim3(fv, Fp, 4.0, pts.view(orbfe.WP_DTYPE), fmpd),
+        lambda: O.fuse_search_sim3(fvo, Fo, 4.0, pts, fmpd), eqp)
+    off1, idx1, off2, idx2, kp2, d2, h1, h2, s1, s2, F12, ep = test_triangulation.scenario(kp, desc, 2, True, False)
+    off1, idx1, off2, idx2 = (np.asarray(x, np.int32) for x in (off1, idx1, off2, idx2))  # not the Python list conversion
+    h1, h2 = h1.astype(np.uint8), h2.astype(np.uint8)
+    row("orbfe_match_triangulation", "ORBmatcher.cc:441-676", "N=%d/%d nodes=%d" % (n, len(kp2), len(off1) - 1),
+        lambda: m.SearchForTriangulation(off1, idx1, off2, idx2, kpp, desc, h1, s1, kp2.view(orbfe.KP_DTYPE), d2, h2, s2,
+                                         ex.mvScaleFactor, F12, ep, False, False, True),
+        lambda: O.search_for_triangulation(off1, idx1, off2, idx2, kp, desc, h1, s1, kp2, d2, h2, s2, sf, F12, ep, False,
+                                           False, True), eq2)
+    # SearchBySim3
+    sc = T3.sim3_scenario(kp, desc, sf, 1)
+    d12o, d21o, d12, d21 = O.Sim3Dir(), O.Sim3Dir(), orbfe.Sim3View(), orbfe.Sim3View()
+    sc["fill12"](d12o, T3.SN_O), sc["fill21"](d21o, T3.SN_O), sc["fill12"](d12, T3.SN_P), sc["fill21"](d21, T3.SN_P)
+    fv2o = O.make_frame_view(sc["kp2"], sc["desc2"], 64, 48, 0.0, 0.0, float(W), float(H), sf)
+    fv2 = orbfe.make_frame_view(sc["kp2"], sc["desc2"], 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    row("orbfe_search_by_sim3", "ORBmatcher.cc:977-1200", "N=%d/%d th=7.5" % (n, len(sc["kp2"])),
+        lambda: m.SearchBySim3(fv, fv2, d12, d21, sc["mp1"].view(orbfe.WP_DTYPE), sc["mpd1"], sc["mp2"].view(orbfe.WP_DTYPE),
+                               sc["mpd2"], 7.5),
+        lambda: O.search_by_sim3(fvo, fv2o, d12o, d21o, sc["mp1"], sc["mpd1"], sc["mp2"], sc["mpd2"], 7.5), eq2)
+    # relocalisation
+    rpts, rmpd, rang, rhas = T3.reloc_scenario(kp, desc, sf, v, M, 2)
+    row("orbfe_match_projection_keyframe", "ORBmatcher.cc:1202-1326", "N=%d M=%d th=12" % (n, M),
+        lambda: m.SearchByProjection_keyframe(fv, Fp, rpts.view(orbfe.WP_DTYPE), rmpd, rang, rhas, 12.0, True),
+        lambda: O.search_by_projection_kf(fvo, Fo, rpts, rmpd, rang, rhas, 12.0, True), eq2)
+    # distinct
+    doff, ddesc = test_distinct.make_sets(3, [int(x) for x in np.random.default_rng(0).integers(2, 30, 500)])
+    row("orbfe_distinctive_descriptors", "MapPoint.cc:343-416", "500 map points, %d observations" % len(ddesc),
+        lambda: m.ComputeDistinctiveDescriptors(doff, ddesc),
+        lambda: O.distinctive_descriptors(doff, ddesc), eqp)
+    # f4
+    t = vs.make_tree(10, 6, seed=16, early_leaf_p=0.02)
+    feats = vs.features_near(t, n, seed=n)
+    voc = orbfe.ORBVocabulary(ex, t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 6)
+    row("orbfe_bow_transform", "TemplatedVocabulary.h:1227-1270", "n=%d k=10 L=6 (%d nodes)" % (n, len(t["wordId"])),
+        lambda: voc.transform(feats, 4),
+        lambda: O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 6, feats, 4),
+        lambda g, c: np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1]))
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(dict(host_cpus=os.cpu_count(), reps=a.reps, rows=rows), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
