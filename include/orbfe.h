@@ -354,6 +354,36 @@ int orbfe_distinctive_descriptors(orbfe_handle *h, int n_sets, const int *set_of
                                   int *best_idx_out, int *best_median_out);
 
 /* -------------------------------------------------------------------------------------------
+ * Node-side image preparation (honourable mention): undistort + resize + grey
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orbfe_prep orbfe_prep;
+
+/* Uploads the undistortion maps the node builds with cv::fisheye::initUndistortRectifyMap(..., CV_32F, map1, map2)
+ * (ros2_ws/src/mono-inertial/src/mono_inertial_node.cpp:61-71): map1 / map2 hold src_h x src_w floats (x and y source
+ * coordinates per undistorted pixel, row-major, no padding).  dst_w x dst_h is the size ImageGrabber resizes to
+ * (m_width x m_height, image_grabber.hpp:102). */
+int orbfe_prep_create(orbfe_handle *h, int src_w, int src_h, const float *map1, const float *map2, int dst_w,
+                      int dst_h, orbfe_prep **out);
+void orbfe_prep_destroy(orbfe_prep *p);
+
+/* replaces ImageGrabber::ConvertImageToGPU (ros2_ws/src/mono-inertial/include/image_grabber.hpp:96-110):
+ * cv::cuda::remap(INTER_CUBIC, BORDER_CONSTANT 0) + cv::cuda::resize(INTER_LINEAR) + cv::cuda::cvtColor(BGR2GRAY) in
+ * one kernel.  bgr: src_h rows of src_w BGR pixels (3 bytes each), `pitch` bytes per row, HOST pointer (pinned buffers
+ * are read by the DMA engine directly); gray_out: dst_h rows of dst_w bytes, HOST pointer.  Arithmetic: SPEC DECISION S9
+ *  -- parity against OpenCV-CUDA is unpinned (third-party arithmetic, absent here). */
+int orbfe_prepare_image(orbfe_handle *h, orbfe_prep *p, const uint8_t *bgr, int pitch, uint8_t *gray_out,
+                        int gray_pitch);
+/* Same with DEVICE pointers, asynchronous on `stream` (NULL == the handle's stream). */
+int orbfe_prepare_image_device(orbfe_handle *h, orbfe_prep *p, const uint8_t *d_bgr, int pitch, uint8_t *d_gray,
+                               int gray_pitch, void *stream);
+/* ConvertImageToGPU followed by ORBextractor::extractFeatures (what the node and Frame::ExtractORB do back to back,
+ * image_grabber.hpp:160 -> src/Frame.cc:178-189) without the grey image leaving the device: the prepared frame is
+ * written straight into the extractor's level-0 rows.  The handle must have been created for dst_w x dst_h images.
+ * gray_out (optional, may be NULL) receives the grey frame as well (the tracker keeps it for the viewer). */
+int orbfe_prepare_and_extract(orbfe_handle *h, orbfe_prep *p, const uint8_t *bgr, int pitch, orbfe_keypoint *kp_out,
+                              uint8_t *desc_out, int *n_out, int *per_level, uint8_t *gray_out, int gray_pitch);
+
+/* -------------------------------------------------------------------------------------------
  * Vocabulary tree: the per-feature part of Frame::ComputeBoW
  * ---------------------------------------------------------------------------------------- */
 typedef struct orbfe_vocab orbfe_vocab;

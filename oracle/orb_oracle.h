@@ -187,6 +187,12 @@ int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const
 void orc_distinctive_descriptors(int nSets, const int *setOff, const uint8_t *desc, int *bestIdxOut,
                                  int *bestMedianOut);
 
+/* node-side image preparation (image_grabber.hpp:96-110), SPEC DECISION S9 -- see prep_oracle.c */
+void orc_prep_remap_pixel(const uint8_t *bgr, int pitch, int srcW, int srcH, float x, float y, uint8_t out[3]);
+float orc_prep_scale(int srcN, int dstN);
+void orc_prepare_image(const uint8_t *bgr, int pitch, int srcW, int srcH, const float *map1, const float *map2, int dstW,
+                       int dstH, uint8_t *grey, int greyPitch, uint8_t *und);
+
 /* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:157-176,470-480): linear cell per kp or -1 */
 void orc_assign_grid(const orc_frame_view *F, int *cellOut);
 

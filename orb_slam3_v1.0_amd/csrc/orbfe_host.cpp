@@ -18,6 +18,7 @@
 #include "launch.h"
 #include "match.h"
 #include "match_common.h"
+#include "prep.h"
 #include "vocab.h"
 
 using namespace orbfe;
@@ -889,6 +890,160 @@ int orbfe_distinctive_descriptors(orbfe_handle* h, int n_sets, const int* set_of
     const int rc = distinctive_run(h->match, h->stream, n_sets, set_off, desc, best_idx_out, best_median_out, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node-side image preparation (image_grabber.hpp:96-110): kernels_prep.hip
+// ---------------------------------------------------------------------------------------------
+struct orbfe_prep {
+    int device = 0;
+    int srcW = 0, srcH = 0, dstW = 0, dstH = 0;
+    float* dMap1 = nullptr;
+    float* dMap2 = nullptr;
+    uint8_t* dSrc = nullptr;   // srcH x srcPitch, BGR
+    uint8_t* hSrc = nullptr;   // pinned staging for pageable sources
+    int srcPitch = 0;
+    uint8_t* dGray = nullptr;  // dstH x grayPitch
+    uint8_t* hGray = nullptr;  // pinned
+    int grayPitch = 0;
+};
+
+void orbfe_prep_destroy(orbfe_prep* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->dMap1) (void)hipFree(p->dMap1);
+    if (p->dMap2) (void)hipFree(p->dMap2);
+    if (p->dSrc) (void)hipFree(p->dSrc);
+    if (p->dGray) (void)hipFree(p->dGray);
+    if (p->hSrc) (void)hipHostFree(p->hSrc);
+    if (p->hGray) (void)hipHostFree(p->hGray);
+    delete p;
+}
+
+int orbfe_prep_create(orbfe_handle* h, int src_w, int src_h, const float* map1, const float* map2, int dst_w, int dst_h,
+                      orbfe_prep** out)
+{
+    if (!h || !map1 || !map2 || !out || src_w < 2 || src_h < 2 || dst_w < 1 || dst_h < 1 || src_w > 16384 || src_h > 16384 ||
+        dst_w > 16384 || dst_h > 16384)
+        return ORBFE_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    orbfe_prep* p = new (std::nothrow) orbfe_prep();
+    if (!p) return ORBFE_ERR_OUT_OF_MEMORY;
+    p->device = h->device;
+    p->srcW = src_w; p->srcH = src_h; p->dstW = dst_w; p->dstH = dst_h;
+    p->srcPitch = (int)align_up((size_t)src_w * 3, 256);
+    p->grayPitch = (int)align_up((size_t)dst_w, 256);
+    const size_t mapBytes = (size_t)src_w * src_h * sizeof(float);
+    bool ok = hipMalloc(&p->dMap1, mapBytes) == hipSuccess && hipMalloc(&p->dMap2, mapBytes) == hipSuccess &&
+              hipMalloc(&p->dSrc, (size_t)p->srcPitch * src_h) == hipSuccess &&
+              hipHostMalloc(&p->hSrc, (size_t)p->srcPitch * src_h) == hipSuccess &&
+              hipMalloc(&p->dGray, (size_t)p->grayPitch * dst_h) == hipSuccess &&
+              hipHostMalloc(&p->hGray, (size_t)p->grayPitch * dst_h) == hipSuccess;
+    ok = ok && hipMemcpy(p->dMap1, map1, mapBytes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->dMap2, map2, mapBytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        orbfe_prep_destroy(p);
+        h->err = "orbfe_prep_create: allocation or map upload failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    *out = p;
+    return ORBFE_OK;
+}
+
+static orbfe::PrepArgs prep_args(const orbfe_prep* p, const uint8_t* dSrc, int srcPitch, uint8_t* dDst, int dstPitch)
+{
+    orbfe::PrepArgs P{};
+    P.src = dSrc; P.srcPitch = srcPitch; P.srcFrameStride = 0;
+    P.srcW = p->srcW; P.srcH = p->srcH;
+    P.map1 = p->dMap1; P.map2 = p->dMap2;
+    P.dst = dDst; P.dstPitch = dstPitch; P.dstFrameStride = 0;
+    P.dstW = p->dstW; P.dstH = p->dstH;
+    P.fx = orbfe::prep_scale(p->srcW, p->dstW);
+    P.fy = orbfe::prep_scale(p->srcH, p->dstH);
+    return P;
+}
+
+// BGR frame -> p->dSrc on stream s (pinned sources go straight through the DMA engine with their own pitch)
+static int prep_upload(orbfe_handle* h, orbfe_prep* p, const uint8_t* bgr, int pitch, hipStream_t s, int* devPitch)
+{
+    const size_t rowBytes = (size_t)p->srcW * 3;
+    hipPointerAttribute_t attr;
+    const bool pinned = pitch <= p->srcPitch && hipPointerGetAttributes(&attr, bgr) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    if (pinned) {
+        HIPCHK(h, hipMemcpyAsync(p->dSrc, bgr, (size_t)pitch * (p->srcH - 1) + rowBytes, hipMemcpyHostToDevice, s));
+        *devPitch = pitch;
+    } else {
+        for (int y = 0; y < p->srcH; y++) memcpy(p->hSrc + (size_t)y * p->srcPitch, bgr + (size_t)y * pitch, rowBytes);
+        HIPCHK(h, hipMemcpyAsync(p->dSrc, p->hSrc, (size_t)p->srcPitch * p->srcH, hipMemcpyHostToDevice, s));
+        *devPitch = p->srcPitch;
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_prepare_image_device(orbfe_handle* h, orbfe_prep* p, const uint8_t* d_bgr, int pitch, uint8_t* d_gray, int gray_pitch,
+                               void* stream)
+{
+    if (!h || !p || !d_bgr || !d_gray || pitch < p->srcW * 3 || gray_pitch < p->dstW) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    orbfe::prep_launch(s, prep_args(p, d_bgr, pitch, d_gray, gray_pitch), 1);
+    HIPCHK(h, hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_prepare_image(orbfe_handle* h, orbfe_prep* p, const uint8_t* bgr, int pitch, uint8_t* gray_out, int gray_pitch)
+{
+    if (!h || !p || !bgr || !gray_out || pitch < p->srcW * 3 || gray_pitch < p->dstW) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int devPitch = 0;
+    const int rc = prep_upload(h, p, bgr, pitch, s, &devPitch);
+    if (rc != ORBFE_OK) return rc;
+    orbfe::prep_launch(s, prep_args(p, p->dSrc, devPitch, p->dGray, p->grayPitch), 1);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(p->hGray, p->dGray, (size_t)p->grayPitch * p->dstH, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int y = 0; y < p->dstH; y++) memcpy(gray_out + (size_t)y * gray_pitch, p->hGray + (size_t)y * p->grayPitch, (size_t)p->dstW);
+    return ORBFE_OK;
+}
+
+int orbfe_prepare_and_extract(orbfe_handle* h, orbfe_prep* p, const uint8_t* bgr, int pitch, orbfe_keypoint* kp_out,
+                              uint8_t* desc_out, int* n_out, int* per_level, uint8_t* gray_out, int gray_pitch)
+{
+    if (!h || !p || !bgr || !kp_out || !desc_out || !n_out || pitch < p->srcW * 3 || (gray_out && gray_pitch < p->dstW))
+        return ORBFE_ERR_INVALID_ARG;
+    if (p->dstW != h->prm.image_width || p->dstH != h->prm.image_height) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int devPitch = 0;
+    int rc = prep_upload(h, p, bgr, pitch, s, &devPitch);
+    if (rc != ORBFE_OK) return rc;
+    // the grey frame is written straight into the extractor's level-0 input rows: no host round trip in between
+    orbfe::prep_launch(s, prep_args(p, p->dSrc, devPitch, h->dIn, h->dInPitch), 1);
+    HIPCHK(h, hipGetLastError());
+    rc = extract_host_enqueue(h, 1, h->dInPitch, s);
+    if (rc != ORBFE_OK) return rc;
+    if (gray_out)
+        HIPCHK(h, hipMemcpy2DAsync(p->hGray, p->grayPitch, h->dIn, h->dInPitch, p->dstW, p->dstH, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    rc = check_device_flags(h, 1);
+    if (rc != ORBFE_OK) return rc;
+    const int n = h->hN[0];
+    n_out[0] = n;
+    memcpy(kp_out, h->hKp, (size_t)n * sizeof(orbfe_keypoint));
+    memcpy(desc_out, h->hDesc, (size_t)n * ORBFE_DESC_BYTES);
+    if (per_level) memcpy(per_level, h->hPer, h->nLevels * sizeof(int));
+    if (gray_out)
+        for (int y = 0; y < p->dstH; y++) memcpy(gray_out + (size_t)y * gray_pitch, p->hGray + (size_t)y * p->grayPitch, (size_t)p->dstW);
+    return ORBFE_OK;
 }
 
 struct orbfe_vocab {

@@ -77,6 +77,7 @@ SYMBOLS = [
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
     "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
+    "orbfe_prep_create", "orbfe_prep_destroy", "orbfe_prepare_image", "orbfe_prepare_image_device", "orbfe_prepare_and_extract",
     "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
 ]
 
@@ -138,6 +139,12 @@ def lib():
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
+    L.orbfe_prep_create.argtypes = [vp, ci, ci, vp, vp, ci, ci, C.POINTER(vp)]
+    L.orbfe_prep_destroy.argtypes = [vp]
+    L.orbfe_prep_destroy.restype = None
+    L.orbfe_prepare_image.argtypes = [vp, vp, vp, ci, vp, ci]
+    L.orbfe_prepare_image_device.argtypes = [vp, vp, vp, ci, vp, ci, vp]
+    L.orbfe_prepare_and_extract.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci]
     L.orbfe_fuse_search_sim3.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
     L.orbfe_search_by_sim3.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Sim3View),
                                        C.POINTER(Sim3View), vp, vp, vp, vp, cf, vp, C.POINTER(ci)]
@@ -463,6 +470,66 @@ class ORBmatcher:
                                            _p(fAngle), nnRatio, int(checkOrientation), _p(out), C.byref(n)),
                     "orbfe_match_bow")
         return n.value, out[:len(fDesc)].copy()
+
+
+class ImagePreparer:
+    """ImageGrabber::ConvertImageToGPU (ros2_ws/src/mono-inertial/include/image_grabber.hpp:96-110): fisheye remap
+    (INTER_CUBIC) + resize (INTER_LINEAR) + BGR2GRAY as one kernel; `extract` chains ORBextractor::extractFeatures
+    without the grey frame leaving the device."""
+
+    def __init__(self, extractor, map1, map2, dst_w, dst_h):
+        self.e = extractor
+        self.L = extractor.L
+        map1 = np.ascontiguousarray(map1, np.float32)
+        map2 = np.ascontiguousarray(map2, np.float32)
+        assert map1.ndim == 2 and map1.shape == map2.shape
+        self.src_h, self.src_w = map1.shape
+        self.dst_w, self.dst_h = int(dst_w), int(dst_h)
+        self.p = C.c_void_p()
+        extractor._chk(self.L.orbfe_prep_create(extractor.h, self.src_w, self.src_h, _p(map1), _p(map2), self.dst_w,
+                                                self.dst_h, C.byref(self.p)), "orbfe_prep_create")
+
+    def close(self):
+        if self.p:
+            self.L.orbfe_prep_destroy(self.p)
+            self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _bgr(self, bgr):
+        assert bgr.dtype == np.uint8 and bgr.ndim == 3 and bgr.shape == (self.src_h, self.src_w, 3) and bgr.strides[2] == 1 \
+            and bgr.strides[1] == 3
+        return bgr, bgr.strides[0]
+
+    def prepare(self, bgr):
+        bgr, pitch = self._bgr(bgr)
+        out = np.zeros((self.dst_h, self.dst_w), np.uint8)
+        self.e._chk(self.L.orbfe_prepare_image(self.e.h, self.p, bgr.ctypes.data, pitch, _p(out), self.dst_w),
+                    "orbfe_prepare_image")
+        return out
+
+    def prepare_device(self, d_bgr, pitch, d_gray, gray_pitch, stream=None):
+        self.e._chk(self.L.orbfe_prepare_image_device(self.e.h, self.p, d_bgr, pitch, d_gray, gray_pitch, stream),
+                    "orbfe_prepare_image_device")
+
+    def extract(self, bgr, want_gray=False):
+        """-> (keypoints, descriptors[, grey]) or None when the frame has no keypoints (as extractFeatures)."""
+        bgr, pitch = self._bgr(bgr)
+        cap = self.e.cap
+        kp = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        per = np.zeros(self.e.nlevels, np.int32)
+        gray = np.zeros((self.dst_h, self.dst_w), np.uint8) if want_gray else None
+        self.e._chk(self.L.orbfe_prepare_and_extract(self.e.h, self.p, bgr.ctypes.data, pitch, _p(kp), _p(desc), C.byref(n),
+                                                     _p(per), _p(gray), self.dst_w), "orbfe_prepare_and_extract")
+        if n.value == 0:
+            return None
+        return (kp[:n.value], desc[:n.value], gray) if want_gray else (kp[:n.value], desc[:n.value])
 
 
 class ORBVocabulary:

@@ -55,7 +55,7 @@ def lib():
     global _lib
     if _lib is None:
         path = os.path.join(ODIR, "liborb_oracle.so")
-        srcs = ("orb_oracle.c", "match_oracle.c", "orb_oracle.h")
+        srcs = ("orb_oracle.c", "match_oracle.c", "prep_oracle.c", "orb_oracle.h")
         if os.environ.get("ORB_ORACLE_ASAN"):  # tests/test_oracle_asan.py: the sanitizer build of the same sources
             path = build(asan=True)
         elif not os.path.exists(path) or any(
@@ -99,6 +99,12 @@ def lib():
         L.orc_is_in_frustum.restype = None
         L.orc_fuse_search.argtypes = [C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
         L.orc_fuse_search.restype = None
+        L.orc_prepare_image.argtypes = [vp, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp]
+        L.orc_prepare_image.restype = None
+        L.orc_prep_remap_pixel.argtypes = [vp, ci, ci, ci, cf, cf, vp]
+        L.orc_prep_remap_pixel.restype = None
+        L.orc_prep_scale.argtypes = [ci, ci]
+        L.orc_prep_scale.restype = cf
         L.orc_fuse_search_sim3.argtypes = [C.POINTER(FrameView), C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
         L.orc_fuse_search_sim3.restype = None
         L.orc_search_by_sim3.argtypes = [C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Sim3Dir),
@@ -325,6 +331,23 @@ def fuse_search(kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
     bd = np.zeros(max(M, 1), np.int32)
     lib().orc_fuse_search(C.byref(kf_view), _p(is2), _p(ur), C.byref(frustum), th, M, _p(points), _p(mpDesc), _p(bi), _p(bd))
     return bi[:M], bd[:M]
+
+
+def prepare_image(bgr, map1, map2, dst_w, dst_h, want_undistorted=False):
+    """ImageGrabber::ConvertImageToGPU (image_grabber.hpp:96-110), SPEC DECISION S9."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    map1 = np.ascontiguousarray(map1, np.float32)
+    map2 = np.ascontiguousarray(map2, np.float32)
+    h, w = map1.shape
+    assert bgr.shape == (h, w, 3)
+    grey = np.zeros((dst_h, dst_w), np.uint8)
+    und = np.zeros((h, w, 3), np.uint8) if want_undistorted else None
+    lib().orc_prepare_image(bgr.ctypes.data, w * 3, w, h, _p(map1), _p(map2), dst_w, dst_h, _p(grey), dst_w, _p(und))
+    return (grey, und) if want_undistorted else grey
+
+
+def prep_scale(src_n, dst_n):
+    return np.float32(lib().orc_prep_scale(src_n, dst_n))
 
 
 def fuse_search_sim3(kf_view, frustum, th, points, mpDesc):
