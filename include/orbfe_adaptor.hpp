@@ -144,6 +144,63 @@ private:
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
 
+// The image half of ORB_SLAM3::ImageGrabber (ros2_ws/src/mono-inertial/include/image_grabber.hpp:38-49,96-110): the
+// undistortion maps are uploaded once (the node passes two cv::cuda::GpuMat built from
+// cv::fisheye::initUndistortRectifyMap, mono_inertial_node.cpp:61-71), ConvertImageToGPU turns a BGR camera frame into
+// the grey frame the tracker consumes.  extractFeatures() chains the extractor without the grey frame leaving the device.
+class ImagePreparer {
+public:
+    ImagePreparer(ORBextractor& extractor, int srcWidth, int srcHeight, const float* map1, const float* map2, int width, int height)
+        : h_(extractor.handle()), cap_(extractor.maxKeypoints()), w_(width), h2_(height)
+    {
+        orbfe_detail::check(orbfe_prep_create(h_, srcWidth, srcHeight, map1, map2, width, height, &p_), h_, "orbfe_prep_create");
+    }
+    ~ImagePreparer() { orbfe_prep_destroy(p_); }
+    ImagePreparer(const ImagePreparer&) = delete;
+    ImagePreparer& operator=(const ImagePreparer&) = delete;
+
+    // image_grabber.hpp:96-110; grey: height rows of `width` bytes
+    std::vector<uint8_t> ConvertImageToGPU(const uint8_t* bgr, int pitch)
+    {
+        std::vector<uint8_t> grey((size_t)w_ * h2_);
+        orbfe_detail::check(orbfe_prepare_image(h_, p_, bgr, pitch, grey.data(), w_), h_, "orbfe_prepare_image");
+        return grey;
+    }
+
+    // ConvertImageToGPU + ORBextractor::extractFeatures (include/ORBextractor.h:62); `greyOut` (optional) receives the frame
+    std::optional<std::tuple<std::shared_ptr<std::vector<KeyPoint>>, std::vector<uint8_t>>> extractFeatures(
+        const uint8_t* bgr, int pitch, std::vector<uint8_t>* greyOut = nullptr)
+    {
+        auto keys = std::make_shared<std::vector<KeyPoint>>(cap_);
+        std::vector<uint8_t> desc((size_t)cap_ * ORBFE_DESC_BYTES);
+        if (greyOut) greyOut->resize((size_t)w_ * h2_);
+        int n = 0;
+        orbfe_detail::check(orbfe_prepare_and_extract(h_, p_, bgr, pitch, reinterpret_cast<orbfe_keypoint*>(keys->data()), desc.data(),
+                                                      &n, nullptr, greyOut ? greyOut->data() : nullptr, w_), h_,
+                            "orbfe_prepare_and_extract");
+        if (n == 0) return std::nullopt;
+        keys->resize(n);
+        desc.resize((size_t)n * ORBFE_DESC_BYTES);
+        return {{keys, std::move(desc)}};
+    }
+
+#ifdef ORBFE_WITH_OPENCV
+    // the reference signature: sensor image in, managed grey HostMem out
+    cv::cuda::HostMem ConvertImageToGPU(const cv::Mat& cv_im)
+    {
+        cv::cuda::HostMem grey(h2_, w_, CV_8UC1, cv::cuda::HostMem::AllocType::SHARED);
+        cv::Mat g = grey.createMatHeader();
+        orbfe_detail::check(orbfe_prepare_image(h_, p_, cv_im.data, (int)cv_im.step, g.data, (int)g.step), h_, "orbfe_prepare_image");
+        return grey;
+    }
+#endif
+
+private:
+    orbfe_handle* h_ = nullptr;
+    orbfe_prep* p_ = nullptr;
+    int cap_ = 0, w_ = 0, h2_ = 0;
+};
+
 // All-static like the reference (include/ORBmatcher.h:40-75); the GPU handle is the extractor's.
 class ORBmatcher {
 public:

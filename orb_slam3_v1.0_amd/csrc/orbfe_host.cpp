@@ -516,44 +516,13 @@ static int extract_host_enqueue(orbfe_handle* h, int batch, int inPitch, hipStre
     return ORBFE_OK;
 }
 
-int orbfe_extract_batch(orbfe_handle* h, const uint8_t* const* grays, int pitch, int batch, orbfe_keypoint* kp_out,
-                        uint8_t* desc_out, int* n_out, int* per_level)
+// extract_host_enqueue, replayed from a hipGraph when possible: every pointer behind the upload is owned by the
+// handle, so the enqueue sequence (memset, 10 kernels, result copy) is captured once per (batch, input pitch) and
+// replayed with a single hipGraphLaunch
+static int extract_enqueue_replay(orbfe_handle* h, int batch, int inPitch, hipStream_t s)
 {
-    if (!h || !grays || !kp_out || !desc_out || !n_out) return ORBFE_ERR_INVALID_ARG;
-    if (batch < 1 || batch > h->maxBatch || pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(h, hipSetDevice(h->device));
-    const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;
-    const size_t inFrame = (size_t)h->dInPitch * H;
-    hipStream_t s = h->stream;
-    // Upload.  Pinned sources (the reference hands over cv::cuda::HostMem, include/ORBextractor.h:62) with a
-    // dword-aligned pitch that fits the device staging rows are copied by the DMA engine straight from the caller's
-    // buffer, keeping the caller's pitch (level 0 is read with an arbitrary pitch anyway); everything else is
-    // re-pitched through the handle's pinned staging block first.
-    bool direct = pitch <= h->dInPitch && (pitch & 3) == 0;
-    for (int b = 0; b < batch; b++) {
-        if (!grays[b]) return ORBFE_ERR_INVALID_ARG;
-        if (direct) {
-            hipPointerAttribute_t attr;
-            if ((reinterpret_cast<uintptr_t>(grays[b]) & 3u) != 0 || hipPointerGetAttributes(&attr, grays[b]) != hipSuccess ||
-                attr.type != hipMemoryTypeHost) {
-                (void)hipGetLastError();
-                direct = false;
-            }
-        }
-    }
-    const int inPitch = direct ? pitch : h->dInPitch;
-    if (direct) {
-        const size_t bytes = (size_t)pitch * (H - 1) + (size_t)W;
-        for (int b = 0; b < batch; b++)
-            HIPCHK(h, hipMemcpyAsync(h->dIn + b * inFrame, grays[b], bytes, hipMemcpyHostToDevice, s));
-    } else {
-        for (int b = 0; b < batch; b++)
-            for (int y = 0; y < H; y++)
-                memcpy(h->hIn + b * inFrame + (size_t)y * h->dInPitch, grays[b] + (size_t)y * pitch, (size_t)W);
-        HIPCHK(h, hipMemcpyAsync(h->dIn, h->hIn, inFrame * batch, hipMemcpyHostToDevice, s));
-    }
-    int rc;
+    const size_t inFrame = (size_t)h->dInPitch * h->prm.image_height;
+    int rc = ORBFE_OK;
     bool viaGraph = h->useGraph && !h->timing && batch < 4096;
     if (viaGraph) {
         // every pointer behind the upload is owned by the handle, so the enqueue sequence (memset, 10 kernels, result
@@ -593,6 +562,48 @@ int orbfe_extract_batch(orbfe_handle* h, const uint8_t* const* grays, int pitch,
         rc = extract_host_enqueue(h, batch, inPitch, s);
         if (rc != ORBFE_OK) return rc;
     }
+    return ORBFE_OK;
+}
+
+int orbfe_extract_batch(orbfe_handle* h, const uint8_t* const* grays, int pitch, int batch, orbfe_keypoint* kp_out,
+                        uint8_t* desc_out, int* n_out, int* per_level)
+{
+    if (!h || !grays || !kp_out || !desc_out || !n_out) return ORBFE_ERR_INVALID_ARG;
+    if (batch < 1 || batch > h->maxBatch || pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;
+    const size_t inFrame = (size_t)h->dInPitch * H;
+    hipStream_t s = h->stream;
+    // Upload.  Pinned sources (the reference hands over cv::cuda::HostMem, include/ORBextractor.h:62) with a
+    // dword-aligned pitch that fits the device staging rows are copied by the DMA engine straight from the caller's
+    // buffer, keeping the caller's pitch (level 0 is read with an arbitrary pitch anyway); everything else is
+    // re-pitched through the handle's pinned staging block first.
+    bool direct = pitch <= h->dInPitch && (pitch & 3) == 0;
+    for (int b = 0; b < batch; b++) {
+        if (!grays[b]) return ORBFE_ERR_INVALID_ARG;
+        if (direct) {
+            hipPointerAttribute_t attr;
+            if ((reinterpret_cast<uintptr_t>(grays[b]) & 3u) != 0 || hipPointerGetAttributes(&attr, grays[b]) != hipSuccess ||
+                attr.type != hipMemoryTypeHost) {
+                (void)hipGetLastError();
+                direct = false;
+            }
+        }
+    }
+    const int inPitch = direct ? pitch : h->dInPitch;
+    if (direct) {
+        const size_t bytes = (size_t)pitch * (H - 1) + (size_t)W;
+        for (int b = 0; b < batch; b++)
+            HIPCHK(h, hipMemcpyAsync(h->dIn + b * inFrame, grays[b], bytes, hipMemcpyHostToDevice, s));
+    } else {
+        for (int b = 0; b < batch; b++)
+            for (int y = 0; y < H; y++)
+                memcpy(h->hIn + b * inFrame + (size_t)y * h->dInPitch, grays[b] + (size_t)y * pitch, (size_t)W);
+        HIPCHK(h, hipMemcpyAsync(h->dIn, h->hIn, inFrame * batch, hipMemcpyHostToDevice, s));
+    }
+    int rc = extract_enqueue_replay(h, batch, inPitch, s);
+    if (rc != ORBFE_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(s));
     rc = check_device_flags(h, batch);
     if (rc != ORBFE_OK) return rc;
@@ -1029,7 +1040,7 @@ int orbfe_prepare_and_extract(orbfe_handle* h, orbfe_prep* p, const uint8_t* bgr
     // the grey frame is written straight into the extractor's level-0 input rows: no host round trip in between
     orbfe::prep_launch(s, prep_args(p, p->dSrc, devPitch, h->dIn, h->dInPitch), 1);
     HIPCHK(h, hipGetLastError());
-    rc = extract_host_enqueue(h, 1, h->dInPitch, s);
+    rc = extract_enqueue_replay(h, 1, h->dInPitch, s);
     if (rc != ORBFE_OK) return rc;
     if (gray_out)
         HIPCHK(h, hipMemcpy2DAsync(p->hGray, p->grayPitch, h->dIn, h->dInPitch, p->dstW, p->dstH, hipMemcpyDeviceToHost, s));

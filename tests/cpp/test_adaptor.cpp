@@ -266,6 +266,21 @@ int main(int argc, char** argv)
         std::printf("sim3 found=%d same=%d fuse3=%d repl=%d added=%d reloc=%d same=%d slot0=%d\n", nSim3, sameSlot, nFuse3, nRepl,
                     nAdded, nReloc, relocSame, rf->mvpMapPoints[0] ? 1 : 0);
     }
+    {  // ImagePreparer: identity maps, dst == src, grey replicated into B, G, R -> the prepared frame is the input frame
+        std::vector<float> m1((size_t)W * H), m2((size_t)W * H);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) { m1[(size_t)y * W + x] = (float)x; m2[(size_t)y * W + x] = (float)y; }
+        std::vector<uint8_t> bgr((size_t)W * H * 3);
+        for (size_t i = 0; i < (size_t)W * H; i++) bgr[3 * i] = bgr[3 * i + 1] = bgr[3 * i + 2] = img[i];
+        ImagePreparer prep(ex, W, H, m1.data(), m2.data(), W, H);
+        const auto grey = prep.ConvertImageToGPU(bgr.data(), W * 3);
+        std::vector<uint8_t> grey2;
+        auto r2 = prep.extractFeatures(bgr.data(), W * 3, &grey2);
+        const bool same = r2 && std::get<0>(*r2)->size() == keys->size() && std::get<1>(*r2) == desc &&
+                          std::memcmp(std::get<0>(*r2)->data(), keys->data(), keys->size() * sizeof(KeyPoint)) == 0;
+        std::printf("prep grey=%d grey2=%d same=%d\n", (int)(std::memcmp(grey.data(), img.data(), img.size()) == 0),
+                    (int)(grey2 == grey), (int)same);
+    }
     std::printf("adaptor ok: %d keypoints, %d matches, levels=%d scale=%g\n", n, nm, ex.GetLevels(), ex.GetScaleFactor());
     return 0;
 }
