@@ -1,4 +1,4 @@
-"""Randomised parity sweep (tools/fuzz_extract.py): random image sizes, pyramid depths, scale factors, thresholds and
+"""Randomised parity sweep (tests/tools/fuzz_extract.py): random image sizes, pyramid depths, scale factors, thresholds and
 budgets; the GPU extractor must equal the oracle bit for bit or refuse the configuration with the documented
 ORBFE_ERR_UNSUPPORTED (portrait images with round(W/H) == 0: the reference divides by zero there)."""
 import os
@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 
 
 @pytest.mark.gpu
@@ -29,7 +29,7 @@ def test_random_configurations_bit_exact(built):
 
 @pytest.mark.gpu
 def test_random_projection_matching_exact(built):
-    """tools/fuzz_match.py: random frame sizes, grids (8x6 ... 257x130), radii, ratios, map-point counts (1 ... 4000),
+    """tests/tools/fuzz_match.py: random frame sizes, grids (8x6 ... 257x130), radii, ratios, map-point counts (1 ... 4000),
     initial claims and far-point filters; match indices must equal the oracle's."""
     import fuzz_match as FM
     rng = np.random.default_rng(4)

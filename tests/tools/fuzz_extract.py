@@ -2,7 +2,7 @@
 """Randomised parity sweep: random image sizes / pyramid depths / scale factors / thresholds / budgets, GPU vs oracle,
 bit for bit (keypoints, descriptors, per-level counts).  usage: fuzz_extract.py [n_configs] [seed]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "orb_slam3_v1.0_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import orbfe

@@ -2,7 +2,7 @@
 """Randomised parity sweep of SearchByProjection: random frame sizes, grids, radii, ratios, map-point counts,
 initial claims and far-point filters; GPU vs oracle, exact match indices.  usage: fuzz_match.py [n] [seed]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "orb_slam3_v1.0_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import orbfe

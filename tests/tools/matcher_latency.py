@@ -4,14 +4,14 @@ H2D, the kernels, one D2H, stream sync) next to the single-thread C oracle on th
 BASELINE config 1 (752x480, ~1000 keypoints).  Results are checked equal before timing.  DESIGN.md section 6
 quotes this table; it is never the bench's `value`.
 
-usage: python3 tools/matcher_latency.py [--reps 200] [--json out.json]"""
+usage: python3 tests/tools/matcher_latency.py [--reps 200] [--json out.json]"""
 import argparse
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "orb_slam3_v1.0_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
