@@ -397,3 +397,65 @@ def test_gpu_reloc_projection_matches_oracle(built, M, th, seed, check, kb8):
     n1r, m1r = O.search_by_projection_kf(fvo, Fo, pts, mpd, ang, None, th, check)
     n1, m1 = m.SearchByProjection_keyframe(fv, Fp, pts.view(orbfe.WP_DTYPE), mpd, ang, None, th, check)
     assert n1 == n1r and np.array_equal(m1, m1r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_random_configurations(built, seed):
+    """Random frame sizes, pyramid depths, grids (8x6 ... 200x150), radii and map-point counts through the three entry
+    points: HIP == oracle on each."""
+    import orbfe
+    from orbfe import synth
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(160, 900)), int(rng.integers(120, 600))
+    levels = int(rng.integers(1, 9))
+    while min(w, h) / 1.2 ** (levels - 1) < 50:
+        levels -= 1
+    args = (int(rng.integers(200, 1500)), 30000, 1.2, levels, 20, 7, w, h)
+    cols, rows = int(rng.integers(8, 201)), int(rng.integers(6, 151))
+    eo = O.Extractor(*args)
+    kp, desc, _ = eo.extract(synth.frame(w, h, 70 + seed))
+    assert len(kp) > 20
+    ex = orbfe.ORBextractor(*args)
+    m = orbfe.ORBmatcher(ex)
+    Fo, Fp = O.Frustum(), orbfe.Frustum()
+    v = FS.fill_frustum(Fo, ON, W=float(w), H=float(h), n_levels=levels, seed=60 + seed)
+    FS.fill_frustum(Fp, PN, W=float(w), H=float(h), n_levels=levels, seed=60 + seed)
+    for F in (Fo, Fp):  # principal point inside this frame
+        F.cx, F.cy = 0.49 * w, 0.52 * h
+    v["cx"], v["cy"] = 0.49 * w, 0.52 * h
+    M = int(rng.integers(1, 3000))
+    th = float(rng.uniform(2.0, 40.0))
+    pts, mpd, ang, has = reloc_scenario(kp, desc, eo.scaleFactors, v, M, seed)
+    fvo = O.make_frame_view(kp, desc, cols, rows, 0.0, 0.0, float(w), float(h), eo.scaleFactors)
+    fv = orbfe.make_frame_view(kp, desc, cols, rows, 0.0, 0.0, float(w), float(h), ex.mvScaleFactor)
+    check = bool(seed & 1)
+    n_r, m_r = O.search_by_projection_kf(fvo, Fo, pts, mpd, ang, has, th, check)
+    n, mm = m.SearchByProjection_keyframe(fv, Fp, pts.view(orbfe.WP_DTYPE), mpd, ang, has, th, check)
+    assert n == n_r and np.array_equal(mm, m_r)
+    bi_r, bd_r = O.fuse_search_sim3(fvo, Fo, th, pts, mpd)
+    bi, bd = m.Fuse_search_sim3(fv, Fp, th, pts.view(orbfe.WP_DTYPE), mpd)
+    assert np.array_equal(bd, bd_r) and np.array_equal(bi, bi_r)
+    # SearchBySim3 on the same key frame pair construction, this frame size / grid
+    global W, H
+    W0, H0 = W, H
+    try:
+        W, H = w, h  # the scenario keeps key frame 2's keypoints inside these bounds
+        sc = sim3_scenario(kp, desc, eo.scaleFactors, seed, n_levels=levels)
+    finally:
+        W, H = W0, H0
+    d12o, d21o, d12, d21 = O.Sim3Dir(), O.Sim3Dir(), orbfe.Sim3View(), orbfe.Sim3View()
+    for D, names in ((d12o, SN_O), (d12, SN_P)):
+        sc["fill12"](D, names)
+        setattr(D, names["max_x"], float(w)), setattr(D, names["max_y"], float(h))
+    for D, names in ((d21o, SN_O), (d21, SN_P)):
+        sc["fill21"](D, names)
+        setattr(D, names["max_x"], float(w)), setattr(D, names["max_y"], float(h))
+    if len(sc["kp2"]) == 0:
+        return
+    fv2o = O.make_frame_view(sc["kp2"], sc["desc2"], cols, rows, 0.0, 0.0, float(w), float(h), eo.scaleFactors)
+    fv2 = orbfe.make_frame_view(sc["kp2"], sc["desc2"], cols, rows, 0.0, 0.0, float(w), float(h), ex.mvScaleFactor)
+    ns_r, ms_r = O.search_by_sim3(fvo, fv2o, d12o, d21o, sc["mp1"], sc["mpd1"], sc["mp2"], sc["mpd2"], th)
+    ns, ms = m.SearchBySim3(fv, fv2, d12, d21, sc["mp1"].view(orbfe.WP_DTYPE), sc["mpd1"], sc["mp2"].view(orbfe.WP_DTYPE),
+                            sc["mpd2"], th)
+    assert ns == ns_r and np.array_equal(ms, ms_r)
