@@ -58,10 +58,12 @@ def test_projection_adversarial_claim_chain(built):
     assert n == n_ref and np.array_equal(out, out_ref)
 
 
-def test_projection_batch_device_equals_host_api(built):
+@pytest.mark.parametrize("B,M", [(3, 800), (24, 1500)])  # small launch: wave-per-map-point top-K; large: thread-per-map-point
+def test_projection_batch_device_equals_host_api(built, B, M):
     import torch
     orbfe, ex, e, kp0, desc0 = _setup()
-    B, M = 3, 800
+    if B > 4:
+        ex = orbfe.ORBextractor(1000, 40000, 1.2, 8, 20, 7, 752, 480, device=0, max_batch=B)
     ims = [synth.frame(752, 480, 20 + b) for b in range(B)]
     res = ex.extract_batch(ims)
     cap = ex.cap
@@ -127,7 +129,7 @@ def test_descriptor_distance_host(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("th,nn,M,seed", [(20.0, 0.85, 3000, 11), (6.0, 0.9, 1500, 12)])
+@pytest.mark.parametrize("th,nn,M,seed", [(20.0, 0.85, 3000, 11), (6.0, 0.9, 1500, 12), (10.0, 0.85, 33000, 13)])  # the last: >= 128 top-K blocks
 def test_projection_large_frame_paths(built, th, nn, M, seed):
     """Frames with more than 2048 keypoints take the other code paths: global-memory sort of the visit order,
     top-K segments that do not fit the LDS tile, claim table in global memory."""

@@ -374,7 +374,8 @@ def test_gpu_search_by_sim3_matches_oracle(built, seed, th, n_keep):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,th,seed,check,kb8", [(2000, 12.0, 1, True, False), (2000, 12.0, 2, False, False),
                                                  (5000, 25.0, 3, True, False), (1, 12.0, 4, True, False),
-                                                 (1500, 12.0, 5, True, True), (3000, 60.0, 6, True, False)])
+                                                 (1500, 12.0, 5, True, True), (3000, 60.0, 6, True, False),
+                                                 (40000, 6.0, 7, True, False)])  # >= 128 blocks: the thread-per-map-point top-K
 def test_gpu_reloc_projection_matches_oracle(built, M, th, seed, check, kb8):
     import orbfe
     eo, kp, desc = extraction(40 + seed)
