@@ -178,6 +178,38 @@ __device__ __forceinline__ void block_sort_keys(unsigned long long* sKeys, unsig
     }
 }
 
+// The same network for P <= 1024 with ONE key per thread held in a register: the exchanges at distance < 64 stay inside
+// a wave (lane shuffles, no barrier); only distances >= 64 go through LDS, double-buffered in the two halves of sKeys
+// (one barrier per pass).  For P = 1024 that is 10 barriers instead of 55 -- the sort is latency, not work.
+// Leaves the sorted keys in sKeys[0..P) like block_sort_keys<true>.
+template <class KeyFn>
+__device__ __forceinline__ void block_sort_keys_reg(unsigned long long* sKeys, int n, int P, int tid, KeyFn keyOf)
+{
+    unsigned long long key = tid < n ? keyOf(tid) : ~0ull;
+    int buf = 0;
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            unsigned long long other;
+            if (j2 >= 64) {
+                unsigned long long* b = sKeys + buf * 1024;
+                b[tid] = key;
+                __syncthreads();
+                other = b[tid ^ j2];
+                buf ^= 1;
+            } else {
+                other = shfl_xor_u64(key, j2);
+            }
+            const bool up = (tid & k2) == 0;
+            const bool lower = (tid & j2) == 0;
+            const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+            key = (lower == up) ? mn : mx;
+        }
+    }
+    __syncthreads();  // the last LDS pass may still be read by others
+    sKeys[tid] = key;
+    __syncthreads();
+}
+
 constexpr int kCellBits = 22;  // kMaxCells
 
 template <bool LDS>
@@ -208,8 +240,10 @@ __device__ __forceinline__ void proj_grid_body(const ProjArgs& A)
         return v;
     };
     // sort 1: visit order (cell x, cell y, index) -> rank
-    block_sort_keys<LDS>(sKeys, gKeys, n, P, tid,
-                         [&](int j) { return ((unsigned long long)cellOf(j) << kRankBits) | (unsigned long long)j; });
+    auto key1 = [&](int j) { return ((unsigned long long)cellOf(j) << kRankBits) | (unsigned long long)j; };
+    const bool regSort = LDS && P <= 1024;  // block-uniform
+    if (regSort) block_sort_keys_reg(sKeys, n, P, tid, key1);
+    else block_sort_keys<LDS>(sKeys, gKeys, n, P, tid, key1);
     for (int r = tid; r < n; r += 1024) {
         unsigned long long key;
         if constexpr (LDS) key = sKeys[r];
@@ -222,10 +256,12 @@ __device__ __forceinline__ void proj_grid_body(const ProjArgs& A)
     }
     __syncthreads();
     // sort 2: storage order (level, cell x, cell y, index)
-    block_sort_keys<LDS>(sKeys, gKeys, n, P, tid, [&](int j) {
+    auto key2 = [&](int j) {
         const unsigned long long lvl = (unsigned long long)min(max(kp[j].octave, 0), 31);
         return (lvl << (kRankBits + kCellBits + 1)) | ((unsigned long long)cellOf(j) << kRankBits) | (unsigned long long)j;
-    });
+    };
+    if (regSort) block_sort_keys_reg(sKeys, n, P, tid, key2);
+    else block_sort_keys<LDS>(sKeys, gKeys, n, P, tid, key2);
     const unsigned long long* desc = reinterpret_cast<const unsigned long long*>(A.desc + (size_t)f * A.kpStride * 32);
     for (int p = tid; p < n; p += 1024) {
         unsigned long long key;
