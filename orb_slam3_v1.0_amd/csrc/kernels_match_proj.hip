@@ -332,13 +332,24 @@ __device__ __forceinline__ void proj_sort_body(const ProjArgs& A)
     const orbfe_map_point* mps = A.mps + (size_t)f * A.M;
     for (int i = tid; i < A.M; i += 1024) atomicAdd(&sHist[sort_bucket(A, mps[i])], 1);
     __syncthreads();
-    if (tid == 0) {  // exclusive prefix in place (1537 entries, once per frame)
-        int acc = 0;
-        for (int b = 0; b < kSortBuckets; b++) {
-            const int c = sHist[b];
-            sHist[b] = acc;
-            acc += c;
+    {  // exclusive prefix in place: two buckets per thread, wave scan by shuffles, 16 wave totals through LDS
+        static_assert(kSortBuckets <= 2048, "two buckets per thread");
+        __shared__ int sWaveTot[16];
+        const int b0 = 2 * tid, b1 = 2 * tid + 1;
+        const int c0 = b0 < kSortBuckets ? sHist[b0] : 0, c1 = b1 < kSortBuckets ? sHist[b1] : 0;
+        const int lane = tid & 63, wv = tid >> 6;
+        int incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
         }
+        if (lane == 63) sWaveTot[wv] = incl;
+        __syncthreads();
+        int base = incl - (c0 + c1);
+        for (int q = 0; q < wv; q++) base += sWaveTot[q];
+        if (b0 < kSortBuckets) sHist[b0] = base;
+        if (b1 < kSortBuckets) sHist[b1] = base + c0;
     }
     __syncthreads();
     for (int i = tid; i < A.M; i += 1024) {
@@ -913,14 +924,16 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
             }
             __syncthreads();
             {
-                const int nFb = sFbCount;
-                for (int q = tid >> 6; q < nFb; q += kResolveThreads / 64) {  // one wave per starved map point
-                    uint32_t a1, a2;
-                    full_scan_top2_wave<LDS>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
-                    if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
+                const int nFb = sFbCount;  // block-uniform
+                if (nFb > 0) {
+                    for (int q = tid >> 6; q < nFb; q += kResolveThreads / 64) {  // one wave per starved map point
+                        uint32_t a1, a2;
+                        full_scan_top2_wave<LDS>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
+                        if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
+                    }
+                    __syncthreads();
                 }
             }
-            __syncthreads();
             if (slot >= 0) { k1 = sFbK1[slot]; k2 = sFbK2[slot]; }
             if (k1 != kKey32None) {
                 const int bestDist = (int)(k1 >> kRankBits), bestRank = (int)(k1 & kRankMask);
