@@ -96,6 +96,16 @@ def make_map_points(kp, n, desc, M, rng, n_levels, mp_dtype):
     return mps, d
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args_tuple, frames, budget_s, with_match, mp_dtype):
     """Single-thread CPU oracle on a bounded sample of the same stream (extract [+ match])."""
     import oracle_py as O
@@ -322,7 +332,7 @@ def main():
             fps, n = cpu_baseline(cfg, frames[:64], a.cpu_seconds, bool(M), orbfe.MP_DTYPE)
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d frames of the same stream through the single-thread C oracle (%s), "
-                                             "host nproc=%d" % (n, what.split("(")[0].strip(), os.cpu_count())}
+                                             "host CPU %s, nproc=%d" % (n, what.split("(")[0].strip(), host_cpu_model(), os.cpu_count())}
             if a.cpu_threads > 1:
                 fps_all, n_all, used, wall = cpu_baseline_all_cores(cfg, frames[:min(len(frames), 8 * a.cpu_threads)],
                                                                     a.cpu_seconds, bool(M), orbfe.MP_DTYPE, a.cpu_threads)
