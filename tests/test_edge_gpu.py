@@ -182,3 +182,67 @@ def test_pinned_input_fast_path(built):
             assert g[0].tobytes() == ref2[0].tobytes() and np.array_equal(g[1], ref2[1]), pitch
         b = ex2.extract_batch([v2, v2])
         assert b[0][0].tobytes() == ref2[0].tobytes() and b[1][0].tobytes() == ref2[0].tobytes()
+
+
+def test_sim3_reloc_prep_reject_bad_arguments(built):
+    """Status codes (never aborts) of the entry points added for the remaining ORBmatcher statics and the image
+    preparation: pyramid depth mismatches, unknown camera model, size mismatches, empty inputs."""
+    import frustum_scenarios as FS
+    import orbfe
+    from test_frustum import PN
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=1)
+    m = orbfe.ORBmatcher(ex)
+    kp, desc = ex.extractFeatures(synth.frame(320, 240, 5))
+    fv = orbfe.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, 320.0, 240.0, ex.mvScaleFactor)
+    fv0 = orbfe.make_frame_view(kp[:0], desc[:0], 64, 48, 0.0, 0.0, 320.0, 240.0, ex.mvScaleFactor)
+    F = orbfe.Frustum()
+    FS.fill_frustum(F, PN, W=320.0, H=240.0, n_levels=ex.nlevels, seed=1)
+    pts = np.zeros(5, orbfe.WP_DTYPE)
+    pts["z"], pts["max_distance"], pts["min_distance"] = 3.0, 10.0, 0.1
+    d = np.zeros((5, 32), np.uint8)
+    ang = np.zeros(5, np.float32)
+    # more predicted levels than the frame has scale factors
+    F.n_levels = ex.nlevels + 1
+    for call in (lambda: m.SearchByProjection_keyframe(fv, F, pts, d, ang, None, 10.0, True),
+                 lambda: m.Fuse_search_sim3(fv, F, 4.0, pts, d)):
+        with pytest.raises(orbfe.OrbfeError) as ei:
+            call()
+        assert ei.value.code == 1
+    F.n_levels = ex.nlevels
+    F.camera_model = 7
+    with pytest.raises(orbfe.OrbfeError) as ei:
+        m.SearchByProjection_keyframe(fv, F, pts, d, ang, None, 10.0, True)
+    assert ei.value.code in (1, 2)
+    F.camera_model = 0
+    # empty frame / no points: defined results, no launch
+    n, out = m.SearchByProjection_keyframe(fv0, F, pts, d, ang, None, 10.0, True)
+    assert n == 0 and len(out) == 0
+    bi, bd = m.Fuse_search_sim3(fv0, F, 4.0, pts, d)
+    assert (bi == -1).all() and (bd == 256).all()
+    D = orbfe.Sim3View()
+    D.rcw[0] = D.rcw[4] = D.rcw[8] = 1.0
+    D.sr[0] = D.sr[4] = D.sr[8] = 1.0
+    D.fx = D.fy = 300.0
+    D.cx, D.cy, D.max_x, D.max_y = 160.0, 120.0, 320.0, 240.0
+    D.log_scale_factor, D.n_levels = float(np.log(np.float32(1.2))), ex.nlevels
+    wp = np.zeros(len(kp), orbfe.WP_DTYPE)
+    wp["skip"] = 1
+    n, out = m.SearchBySim3(fv, fv, D, D, wp, desc, wp, desc, 7.5)  # every feature without a map point
+    assert n == 0 and (out == -1).all()
+    n, out = m.SearchBySim3(fv0, fv, D, D, wp[:0], desc[:0], wp, desc, 7.5)
+    assert n == 0 and len(out) == 0
+    D.n_levels = 0
+    with pytest.raises(orbfe.OrbfeError) as ei:
+        m.SearchBySim3(fv, fv, D, D, wp, desc, wp, desc, 7.5)
+    assert ei.value.code == 1
+    # image preparation: map / image / extractor size mismatches
+    m1 = np.zeros((48, 64), np.float32)
+    with pytest.raises(orbfe.OrbfeError):
+        orbfe.ImagePreparer(ex, m1, m1, 0, 10)
+    prep = orbfe.ImagePreparer(ex, m1, m1, 32, 24)
+    with pytest.raises(AssertionError):
+        prep.prepare(np.zeros((48, 63, 3), np.uint8))
+    with pytest.raises(orbfe.OrbfeError) as ei:  # the extractor was created for 320x240 frames
+        prep.extract(np.zeros((48, 64, 3), np.uint8))
+    assert ei.value.code == 1
+    assert prep.prepare(np.full((48, 64, 3), 200, np.uint8)).shape == (24, 32)
