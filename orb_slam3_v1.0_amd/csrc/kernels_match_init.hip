@@ -28,8 +28,9 @@ constexpr int kInitThreads = 1024;
 constexpr int kInitN = 2048;  // frame-2 keypoints that fit the LDS image
 constexpr int kIntMax = 0x7fffffff;
 constexpr int kFastN0 = 1024;     // level-0 keypoints of frame 1 the fast kernel handles
-constexpr int kFastCand = 12288;  // candidate keys that fit the LDS image (reuses frame 2's staging area)
+constexpr int kFastCand = 8192;   // candidate keys of the rows longer than four that fit the LDS image
 
+struct InitRowHdr;
 struct InitArgs {
     int n1, n2;
     const orbfe_keypoint* kp1;
@@ -48,7 +49,8 @@ struct InitArgs {
     int* cell2;       // [n2] scratch
     int* list0;       // [n1] scratch: level-0 keypoints of frame 1 in index order
     int* binOf;       // [n1] scratch: rotation bin pushed for i1, or -1
-    unsigned long long* cand;  // [kFastN0][n2] scratch of the fast kernel: candidate keys per level-0 keypoint of frame 1
+    unsigned long long* cand;  // [n0][n2] scratch of the fast path: candidate keys per level-0 keypoint of frame 1
+    struct InitRowHdr* hdr;    // [n0] row lengths + the four smallest keys
 };
 
 struct InitLds {
@@ -229,151 +231,156 @@ __global__ __launch_bounds__(kInitThreads) void init_match_kernel(InitArgs A)
 
 
 // ---------------------------------------------------------------------------------------------
-// Fast variant (frame 2 fits the LDS image and frame 1 has <= kFastN0 level-0 keypoints): the distances do not
-// depend on the running state, only the skip test "vMatchedDistance[i2] <= dist" (:368-369) does.  So
-//   phase 1 (all 16 waves, one frame-1 keypoint per wave at a time): window + level tests and the Hamming
-//           distance for every frame-2 keypoint -> candidate keys (distance, cell x, cell y, index) per keypoint;
-//   phase 2 (ONE wave, keypoints in index order): lanes take one candidate each, drop those whose target
-//           already holds a match at a distance <= theirs, wave-reduce the two smallest keys, lane 0 applies the
-//           accept / steal update of :383-406.  The candidate lists sit in LDS (the staging area of frame 2 is
-//           dead by then), the per-target state as well, so a step costs a few hundred cycles and no barrier.
+// Fast variant (frame 2 <= kInitN keypoints, frame 1 <= kFastN0 level-0 keypoints).  The distances do not depend
+// on the running state, only the skip test "vMatchedDistance[i2] <= dist" (:368-369) does.  So
+//   init_cand_kernel   (one WAVE per level-0 keypoint of frame 1, spread over the chip): window + level tests and
+//       the Hamming distance for every frame-2 keypoint -> candidate keys (distance, cell x, cell y, index) in a
+//       row per keypoint, plus the row's four smallest keys, sorted;
+//   init_order_kernel  (one block; the order-dependent part runs in ONE wave, keypoints in index order): a
+//       candidate is skipped iff its target already holds a match at a distance <= its own, so the best and
+//       second-best of a step are the first two of the row's sorted keys that pass.  Lanes 0-3 test the four
+//       pre-selected keys: if two pass (or the row has no more than four) the step is decided by a ballot; else
+//       the whole row (in LDS when all rows fit) is wave-reduced.  Lane 0 applies the accept / steal update of
+//       :383-406.  No block barrier inside the ordered loop.
 // Same keys, same order, same float comparisons as init_match_kernel: the results are identical.
 // ---------------------------------------------------------------------------------------------
+struct InitRowHdr {
+    int cnt, pad;
+    unsigned long long top[4];  // the row's smallest keys, ascending, kKeyNone-padded
+};
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void init_cand_kernel(InitArgs A, int n0)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // row == position in frame 1's level-0 list
+    if (t >= n0) return;
+    const int n2 = A.n2;
+    const int i1 = A.list0[t];
+    const orbfe_keypoint k1p = A.kp1[i1];
+    // GetFeaturesInArea(x, y, windowSize, level1, level1) on frame 2, src/Frame.cc:413-435
+    const float x = k1p.x, y = k1p.y, r = A.r;
+    float tt;
+    tt = x - A.minX; tt = tt - r; tt = tt * A.invW;
+    const int minCX = max(0, (int)floorf(tt));
+    tt = x - A.minX; tt = tt + r; tt = tt * A.invW;
+    const int maxCX = min(A.cols - 1, (int)ceilf(tt));
+    tt = y - A.minY; tt = tt - r; tt = tt * A.invH;
+    const int minCY = max(0, (int)floorf(tt));
+    tt = y - A.minY; tt = tt + r; tt = tt * A.invH;
+    const int maxCY = min(A.rows - 1, (int)ceilf(tt));
+    const bool any = !(minCX >= A.cols || maxCX < 0 || minCY >= A.rows || maxCY < 0);
+    const int level1 = k1p.octave;
+    int count = 0;
+    unsigned long long top[4] = {kKeyNone, kKeyNone, kKeyNone, kKeyNone};
+    if (any) {
+        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.desc1 + (size_t)i1 * 32);
+        const unsigned long long d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
+        unsigned long long* row = A.cand + (size_t)t * n2;
+        for (int j0 = 0; j0 < n2; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = j < n2;
+            unsigned long long key = kKeyNone;
+            if (ok) {
+                const orbfe_keypoint k = A.kp2[j];
+                // Frame::PosInGrid (src/Frame.cc:470-480): only the LINEAR index is validated
+                float px = k.x - A.minX; px = px * A.invW;
+                float py = k.y - A.minY; py = py * A.invH;
+                const int posX = (int)roundf(px), posY = (int)roundf(py);
+                const int lin = posY * A.cols + posX;
+                ok = lin >= 0 && lin < A.cols * A.rows;
+                const int cx = ok ? lin % A.cols : 0, cy = ok ? lin / A.cols : 0;
+                if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) ok = false;
+                // bCheckLevels = (minLevel > 0) || (maxLevel >= 0) with minLevel = maxLevel = level1
+                const bool checkLevels = (level1 > 0) || (level1 >= 0);
+                if (checkLevels && (k.octave < level1 || (level1 >= 0 && k.octave > level1))) ok = false;
+                const float dx = k.x - x, dy = k.y - y;
+                if (!(fabsf(dx) < r && fabsf(dy) < r)) ok = false;
+                if (ok) {
+                    const unsigned long long* kd = reinterpret_cast<const unsigned long long*>(A.desc2 + (size_t)j * 32);
+                    const int dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
+                    key = ((unsigned long long)dist << 52) | ((unsigned long long)cx << 36) | ((unsigned long long)cy << 20) |
+                          (unsigned long long)j;
+                }
+            }
+            unsigned long long mask = __ballot(ok);
+            if (ok) row[count + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+            count += __popcll(mask);
+            while (mask) {  // wave-uniform: fold the chunk's keys into the sorted four
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                unsigned long long kk = readlane_u64(key, l);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned long long lo = kk < top[q] ? kk : top[q];
+                    kk = kk < top[q] ? top[q] : kk;
+                    top[q] = lo;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        InitRowHdr h;
+        h.cnt = count;
+        h.pad = 0;
+        h.top[0] = top[0]; h.top[1] = top[1]; h.top[2] = top[2]; h.top[3] = top[3];
+        A.hdr[t] = h;
+    }
+}
+
 struct FastState {
     unsigned short dist[kInitN];    // vMatchedDistance (0xFFFF == INT_MAX)
-    short matched21[kInitN];        // vnMatches21
+    short matched21[kInitN];        // vnMatches21 (position in the level-0 list)
     float angle2[kInitN];
     int i1[kFastN0];                // level-0 keypoints of frame 1 in index order
     float angle1[kFastN0];
     int off[kFastN0];
     int cnt[kFastN0];
+    unsigned long long top[kFastN0][4];
 };
 
-__global__ __launch_bounds__(kInitThreads) void init_match_fast_kernel(InitArgs A)
+__global__ __launch_bounds__(kInitThreads) void init_order_kernel(InitArgs A, int n0)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char sRaw[sizeof(int4) * kInitN + 32 * kInitN];  // frame 2, then candidates
+    __shared__ unsigned long long sCand[kFastCand];
     __shared__ FastState T;
     __shared__ int sHist[ORBFE_HISTO_LENGTH];
     __shared__ int sWave[kInitThreads / 64];
-    __shared__ int sN0, sNm, sTotal, sInd[3];
-    static_assert(sizeof(sRaw) >= (size_t)kFastCand * 8, "candidate image must fit the frame-2 staging area");
-    int4* sKp = reinterpret_cast<int4*>(sRaw);
-    unsigned long long* sDesc = reinterpret_cast<unsigned long long*>(sRaw + sizeof(int4) * kInitN);
-    unsigned long long* sCand = reinterpret_cast<unsigned long long*>(sRaw);
+    __shared__ int sNm, sTotal, sInd[3];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n1 = A.n1, n2 = A.n2;
-
-    // ---- frame 2: grid cell per keypoint (Frame::PosInGrid, src/Frame.cc:470-480) + state ----
     for (int j = tid; j < n2; j += kInitThreads) {
-        const orbfe_keypoint k = A.kp2[j];
-        float px = k.x - A.minX; px = px * A.invW;
-        float py = k.y - A.minY; py = py * A.invH;
-        const int posX = (int)roundf(px), posY = (int)roundf(py);
-        const int lin = posY * A.cols + posX;
-        const int cell = (lin >= 0 && lin < A.cols * A.rows) ? ((lin % A.cols) | ((lin / A.cols) << 16)) : -1;
-        sKp[j] = make_int4(cell, k.octave, __float_as_int(k.x), __float_as_int(k.y));
         T.dist[j] = 0xFFFF;
         T.matched21[j] = -1;
-        T.angle2[j] = k.angle;
+        T.angle2[j] = A.kp2[j].angle;
     }
-    {
-        const unsigned long long* d2 = reinterpret_cast<const unsigned long long*>(A.desc2);
-        for (int j = tid; j < n2 * 4; j += kInitThreads) sDesc[j] = d2[j];
+    for (int i = tid; i < n1; i += kInitThreads) {
+        A.matches12[i] = -1;
+        A.binOf[i] = -1;
+    }
+    for (int t = tid; t < n0; t += kInitThreads) {
+        const int i1 = A.list0[t];
+        const InitRowHdr h = A.hdr[t];
+        T.i1[t] = i1;
+        T.angle1[t] = A.kp1[i1].angle;
+        T.cnt[t] = h.cnt;
+        T.top[t][0] = h.top[0]; T.top[t][1] = h.top[1]; T.top[t][2] = h.top[2]; T.top[t][3] = h.top[3];
     }
     if (tid < ORBFE_HISTO_LENGTH) sHist[tid] = 0;
-    if (tid == 0) { sN0 = 0; sNm = 0; }
+    if (tid == 0) sNm = 0;
     __syncthreads();
-
-    // ---- frame 1: ordered list of level-0 keypoints (level1 > 0 -> continue, :346-347) ----
-    for (int base = 0; base < n1; base += kInitThreads) {
-        const int i = base + tid;
-        float ang = 0.0f;
-        int flag = 0;
-        if (i < n1) {
-            const orbfe_keypoint k = A.kp1[i];
-            flag = k.octave <= 0 ? 1 : 0;
-            ang = k.angle;
-            A.matches12[i] = -1;
-            A.binOf[i] = -1;
-        }
-        int incl = flag;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) sWave[wv] = incl;
-        __syncthreads();
-        int pos = sN0 + incl - flag;
-        for (int q = 0; q < wv; q++) pos += sWave[q];
-        if (flag && pos < kFastN0) {  // the host only selects this kernel when the count fits
-            T.i1[pos] = i;
-            T.angle1[pos] = ang;
-        }
-        __syncthreads();
-        if (tid == kInitThreads - 1) sN0 = pos + flag;
-        __syncthreads();
-    }
-    const int n0 = min(sN0, kFastN0);
-
-    // ---- phase 1: candidate keys of every level-0 keypoint of frame 1 ----
-    for (int t = wv; t < n0; t += kInitThreads / 64) {
-        const int i1 = T.i1[t];
-        const orbfe_keypoint k1p = A.kp1[i1];
-        // GetFeaturesInArea(x, y, windowSize, level1, level1) on frame 2, src/Frame.cc:413-435
-        const float x = k1p.x, y = k1p.y, r = A.r;
-        float tt;
-        tt = x - A.minX; tt = tt - r; tt = tt * A.invW;
-        const int minCX = max(0, (int)floorf(tt));
-        tt = x - A.minX; tt = tt + r; tt = tt * A.invW;
-        const int maxCX = min(A.cols - 1, (int)ceilf(tt));
-        tt = y - A.minY; tt = tt - r; tt = tt * A.invH;
-        const int minCY = max(0, (int)floorf(tt));
-        tt = y - A.minY; tt = tt + r; tt = tt * A.invH;
-        const int maxCY = min(A.rows - 1, (int)ceilf(tt));
-        const bool any = !(minCX >= A.cols || maxCX < 0 || minCY >= A.rows || maxCY < 0);
-        const int level1 = k1p.octave;
-        int count = 0;
-        if (any) {
-            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.desc1 + (size_t)i1 * 32);
-            const unsigned long long d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
-            unsigned long long* row = A.cand + (size_t)t * n2;
-            for (int j0 = 0; j0 < n2; j0 += 64) {
-                const int j = j0 + lane;
-                bool ok = j < n2;
-                unsigned long long key = 0;
-                if (ok) {
-                    const int4 q = sKp[j];
-                    const int cell = q.x, oct = q.y;
-                    const int cx = cell & 0xffff, cy = cell >> 16;
-                    ok = cell >= 0 && !(cx < minCX || cx > maxCX || cy < minCY || cy > maxCY);
-                    // bCheckLevels = (minLevel > 0) || (maxLevel >= 0) with minLevel = maxLevel = level1
-                    const bool checkLevels = (level1 > 0) || (level1 >= 0);
-                    if (checkLevels && (oct < level1 || (level1 >= 0 && oct > level1))) ok = false;
-                    const float dx = __int_as_float(q.z) - x, dy = __int_as_float(q.w) - y;
-                    if (!(fabsf(dx) < r && fabsf(dy) < r)) ok = false;
-                    if (ok) {
-                        const unsigned long long* kd = sDesc + (size_t)j * 4;
-                        const int dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
-                        key = ((unsigned long long)dist << 52) | ((unsigned long long)cx << 36) |
-                              ((unsigned long long)cy << 20) | (unsigned long long)j;
-                    }
-                }
-                const unsigned long long mask = __ballot(ok);
-                if (ok) row[count + __popcll(mask & ((1ull << lane) - 1ull))] = key;
-                count += __popcll(mask);
-            }
-        }
-        if (lane == 0) T.cnt[t] = count;
-    }
-    __syncthreads();  // frame 2's staging area is dead from here on; the candidate rows are visible to the block
-
-    // ---- row offsets; copy the rows into LDS when they fit ----
+    // ---- row offsets (only rows longer than four are ever read in full); copy them into LDS when they fit ----
     {
         int run = 0;
         for (int base = 0; base < n0; base += kInitThreads) {
             const int t = base + tid;
-            const int c = t < n0 ? T.cnt[t] : 0;
+            int c = t < n0 ? T.cnt[t] : 0;
+            if (c <= 4) c = 0;
             int incl = c;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -399,27 +406,46 @@ __global__ __launch_bounds__(kInitThreads) void init_match_fast_kernel(InitArgs 
     if (inLds) {
         for (int t = wv; t < n0; t += kInitThreads / 64) {
             const int c = T.cnt[t], o = T.off[t];
+            if (c <= 4) continue;
             const unsigned long long* row = A.cand + (size_t)t * n2;
             for (int k = lane; k < c; k += 64) sCand[o + k] = row[k];
         }
     }
     __syncthreads();
 
-    // ---- phase 2: the order-dependent part, one wave ----
+    // ---- the order-dependent part, one wave ----
     if (wv == 0) {
         const float factor = 1.0f / ORBFE_HISTO_LENGTH;
         for (int t = 0; t < n0; t++) {
             const int c = T.cnt[t];
-            const unsigned long long* L = inLds ? sCand + T.off[t] : A.cand + (size_t)t * n2;
+            if (c == 0) continue;  // wave-uniform
             unsigned long long k1 = kKeyNone, k2 = kKeyNone;
-            for (int k = lane; k < c; k += 64) {
-                const unsigned long long key = L[k];
-                const int j = (int)(key & 0xFFFFF), dist = (int)(key >> 52);
-                if ((int)T.dist[j] <= dist) continue;  // :368-369 (0xFFFF stands for INT_MAX: never <= a distance)
-                if (key < k1) { k2 = k1; k1 = key; }
-                else if (key < k2) k2 = key;
+            {
+                const unsigned long long key = lane < 4 ? T.top[t][lane] : kKeyNone;
+                bool pass = false;
+                if (key != kKeyNone) {
+                    const int j = (int)(key & 0xFFFFF), dist = (int)(key >> 52);
+                    pass = !((int)T.dist[j] <= dist);  // :368-369 (0xFFFF stands for INT_MAX: never <= a distance)
+                }
+                const unsigned long long m = __ballot(pass);
+                if (__popcll(m) >= 2 || c <= 4) {
+                    if (m) {
+                        k1 = readlane_u64(key, __builtin_ctzll(m));
+                        const unsigned long long m2 = m & (m - 1);
+                        if (m2) k2 = readlane_u64(key, __builtin_ctzll(m2));
+                    }
+                } else {  // fewer than two of the pre-selected keys are usable: reduce the whole row
+                    const unsigned long long* L = inLds ? sCand + T.off[t] : A.cand + (size_t)t * n2;
+                    for (int k = lane; k < c; k += 64) {
+                        const unsigned long long kk = L[k];
+                        const int j = (int)(kk & 0xFFFFF), dist = (int)(kk >> 52);
+                        if ((int)T.dist[j] <= dist) continue;
+                        if (kk < k1) { k2 = k1; k1 = kk; }
+                        else if (kk < k2) k2 = kk;
+                    }
+                    wave_top2(k1, k2);
+                }
             }
-            wave_top2(k1, k2);
             if (lane == 0 && k1 != kKeyNone) {
                 const int bestDist = (int)(k1 >> 52), bestIdx2 = (int)(k1 & 0xFFFFF);
                 const int bestDist2 = k2 == kKeyNone ? kIntMax : (int)(k2 >> 52);
@@ -441,7 +467,7 @@ __global__ __launch_bounds__(kInitThreads) void init_match_fast_kernel(InitArgs 
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // lane 0's LDS updates before the next step's reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // lane 0's LDS updates before the next step's reads
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -490,6 +516,7 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     const size_t oD1 = c.take((size_t)n1 * 32);
     const size_t oKp2 = c.take((size_t)n2 * sizeof(orbfe_keypoint));
     const size_t oD2 = c.take((size_t)n2 * 32);
+    const size_t oL0 = c.take((size_t)n1 * sizeof(int));  // uploaded for the fast path, written by the sequential kernel otherwise
     const size_t inBytes = c.off;
     const size_t oM12 = c.take((size_t)n1 * sizeof(int));
     const size_t oNM = c.take(sizeof(int));
@@ -497,12 +524,12 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     const size_t oM21 = c.take((size_t)n2 * sizeof(int));
     const size_t oMD = c.take((size_t)n2 * sizeof(int));
     const size_t oCell = c.take((size_t)n2 * sizeof(int));
-    const size_t oL0 = c.take((size_t)n1 * sizeof(int));
     const size_t oBin = c.take((size_t)n1 * sizeof(int));
     int n0 = 0;  // level-0 keypoints of frame 1 (:346-347): selects the kernel and sizes its candidate scratch
     for (int i = 0; i < n1; i++) n0 += F1->kp[i].octave <= 0;
     const bool fast = n2 <= kInitN && n0 <= kFastN0;
     const size_t oCand = c.take(fast ? (size_t)std::max(n0, 1) * n2 * sizeof(unsigned long long) : 8);
+    const size_t oHdr = c.take(fast ? (size_t)std::max(n0, 1) * sizeof(InitRowHdr) : 8);
     int rc = ensure(m, c.off, inBytes + outBytes + 256, err);
     if (rc != ORBFE_OK) return rc;
     uint8_t* hp = static_cast<uint8_t*>(m.hpin);
@@ -511,6 +538,11 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     memcpy(hp + oD1, F1->desc, (size_t)n1 * 32);
     memcpy(hp + oKp2, F2->kp, (size_t)n2 * sizeof(orbfe_keypoint));
     memcpy(hp + oD2, F2->desc, (size_t)n2 * 32);
+    if (fast) {  // row t of the candidate pass = t-th level-0 keypoint of frame 1 (level1 > 0 -> continue, :346-347)
+        int* l0 = reinterpret_cast<int*>(hp + oL0);
+        for (int i = 0, t = 0; i < n1; i++)
+            if (F1->kp[i].octave <= 0) l0[t++] = i;
+    }
     MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
     InitArgs A{};
     A.n1 = n1; A.n2 = n2;
@@ -531,8 +563,11 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     A.list0 = reinterpret_cast<int*>(dp + oL0);
     A.binOf = reinterpret_cast<int*>(dp + oBin);
     A.cand = reinterpret_cast<unsigned long long*>(dp + oCand);
-    if (fast && !getenv("ORBFE_INIT_SLOW"))
-        hipLaunchKernelGGL(init_match_fast_kernel, dim3(1), dim3(kInitThreads), 0, s, A);
+    A.hdr = reinterpret_cast<InitRowHdr*>(dp + oHdr);
+    if (fast && !getenv("ORBFE_INIT_SLOW")) {
+        if (n0 > 0) hipLaunchKernelGGL(init_cand_kernel, dim3((n0 + 3) / 4), dim3(256), 0, s, A, n0);
+        hipLaunchKernelGGL(init_order_kernel, dim3(1), dim3(kInitThreads), 0, s, A, n0);
+    }
     else if (n2 <= kInitN)
         hipLaunchKernelGGL(init_match_kernel<true>, dim3(1), dim3(kInitThreads), 0, s, A);
     else
