@@ -142,3 +142,37 @@ def test_projection_large_frame_paths(built, th, nn, M, seed):
     n, out = orbfe.ORBmatcher(ex).SearchByProjection(fv, mps.view(orbfe.MP_DTYPE), mpd, th, False, 0.0, nn, init_obs)
     assert n == n_ref and np.array_equal(out, out_ref)
     assert n_ref > M // 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th,M,reloc", [(40.0, 600, False), (14.0, 900, False), (60.0, 500, True), (25.0, 40000, True)])
+def test_projection_many_survivors(built, th, M, reloc):
+    """Every keypoint descriptor is a near copy of one pattern, so (almost) every keypoint inside a window survives the
+    distance cut-off: hundreds of survivors per map point.  Exercises the list-overflow reduction of the
+    wave-per-map-point top-K pass (> 64 and > 128 survivors), long claim chains and the exact rescans of the
+    resolve pass; the last case takes the thread-per-map-point kernel (>= 128 blocks)."""
+    import frustum_scenarios as FS
+    from test_frustum import ON, PN
+    orbfe, ex, e, kp, desc = _setup()
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    desc = np.stack([S.flip_bits(base, int(rng.integers(0, 14)), rng) for _ in range(len(kp))])
+    m = orbfe.ORBmatcher(ex)
+    fvo = O.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, 752.0, 480.0, e.scaleFactors)
+    fv = orbfe.make_frame_view(kp, desc, 64, 48, 0.0, 0.0, 752.0, 480.0, ex.mvScaleFactor)
+    if not reloc:
+        mps, mpd, init_obs = S.projection_scenario(kp, desc, M, 3, O.MP_DTYPE, NAMES_O, e.nLevels, jitter=6.0, max_flip=10)
+        n_ref, out_ref = O.search_by_projection(fvo, mps, mpd, init_obs, th, 0.95)
+        n, out = m.SearchByProjection(fv, mps.view(orbfe.MP_DTYPE), mpd, th, False, 0.0, 0.95, init_obs)
+        assert n == n_ref and np.array_equal(out, out_ref)
+        assert n_ref > 50
+    else:
+        import test_sim3_reloc as T3
+        Fo, Fp = O.Frustum(), orbfe.Frustum()
+        v = FS.fill_frustum(Fo, ON, seed=77)
+        FS.fill_frustum(Fp, PN, seed=77)
+        pts, mpd, ang, has = T3.reloc_scenario(kp, desc, e.scaleFactors, v, M, 9)
+        n_ref, out_ref = O.search_by_projection_kf(fvo, Fo, pts, mpd, ang, has, th, True)
+        n, out = m.SearchByProjection_keyframe(fv, Fp, pts.view(orbfe.WP_DTYPE), mpd, ang, has, th, True)
+        assert n == n_ref and np.array_equal(out, out_ref)
+        assert n_ref > 50
