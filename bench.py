@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU (128: 131 k, 256: 142 k, 512: 149 k, 1024: 147 k frames/s)")
     ap.add_argument("--workload", default="euroc_752x480", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the all-cores CPU baseline (0/1 = skip)")

@@ -39,7 +39,16 @@ for kn in sorted(set(fetch) | set(write)):
     out["kernels"][kn] = {"launches": len(fetch.get(kn, [])), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                           "hbm_bytes_per_launch": fb + wb}
     print("%-70s n=%3d fetch=%8.1f MB write=%8.1f MB" % (kn[-70:], len(fetch.get(kn, [])), fb / 1e6, wb / 1e6))
-out["_meta"] = {"workload": "euroc_752x480", "frames_per_launch": 256,
+frames_per_launch, workload = 512, "euroc_752x480"  # bench.py defaults; overridden by the bench line of the profiled run
+try:
+    for line in open(os.path.join(root, "bench_FETCH_SIZE.log")):
+        if line.startswith("{"):
+            cfg = json.loads(line)["config"]
+            frames_per_launch = int(cfg["frames_per_step"])
+            workload = cfg["workload"].split(" ")[0]
+except (OSError, ValueError, KeyError):
+    pass
+out["_meta"] = {"workload": workload, "frames_per_launch": frames_per_launch,
                 "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
                 "correction": "FETCH_SIZE x1024 x%.1f, WRITE_SIZE x1024 x%.1f (measured with tools/pmc_calib.bin, 4 B/lane and 16 B/lane streams)"
                               % (calib[("FETCH_SIZE", "copy4")], calib[("WRITE_SIZE", "copy4")])}
