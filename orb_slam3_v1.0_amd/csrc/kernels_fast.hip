@@ -41,20 +41,20 @@ constexpr int kScPitch = 68;
 constexpr int kMaxTileCand = (kFastTW / 2) * (kFastTH / 2);  // strict 8-neighbour maxima: <= 1 per 2x2
 constexpr int kTmpH = kFastTH + 4;                        // 36 rows of horizontal blur sums
 
-// max over the 16 circular 9-arcs of the minimum of a[] over the arc
+// max over the 16 circular 9-arcs of the minimum of a[] over the arc.  Three-input min / max (v_min3_i32, v_max3_i32):
+// t[k] = min of 3 consecutive, arc minimum = min3(t[k], t[k+3], t[k+6]) -- 32 + 8 instructions instead of 64 + 16.
 __device__ __forceinline__ int arc_max_min(const int (&a)[16])
 {
-    int m2[16], m4[16], m8[16];
+    int t[16], m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = min(a[k], a[(k + 1) & 15]);
+    for (int k = 0; k < 16; k++) t[k] = min(min(a[k], a[(k + 1) & 15]), a[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+    for (int k = 0; k < 16; k++) m9[k] = min(min(t[k], t[(k + 3) & 15]), t[(k + 6) & 15]);
+    int g[6];
 #pragma unroll
-    for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
-    int best = -256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) best = max(best, min(m8[k], a[(k + 8) & 15]));
-    return best;
+    for (int k = 0; k < 5; k++) g[k] = max(max(m9[3 * k], m9[3 * k + 1]), m9[3 * k + 2]);
+    g[5] = m9[15];
+    return max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), g[5]));
 }
 
 // stage A: compass points = ring bits 0 (+3,0), 4 (0,+3), 8 (-3,0), 12 (0,-3).  Nine consecutive
@@ -118,7 +118,7 @@ __device__ __forceinline__ int corner_score(const int (&d)[16], bool pb, bool pd
     const int sgn = pb ? 1 : -1;
     int a[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = sgn * d[k];
+    for (int k = 0; k < 16; k++) a[k] = __mul24(sgn, d[k]);  // |d| <= 255: the 24-bit multiply is full rate
     int best = arc_max_min(a);
     if (pb && pd) {
 #pragma unroll
@@ -432,9 +432,11 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                     s = sScore[sy][sx];
                     hi = s >= iniTh;
                     atomicAdd(&sRow[oy], hi ? 0x10001u : 1u);  // only read by the exact-cap path of the quadtree kernel
-                    keep = s > sScore[sy - 1][sx - 1] && s > sScore[sy - 1][sx] && s > sScore[sy - 1][sx + 1] &&
-                           s > sScore[sy][sx - 1] && s > sScore[sy][sx + 1] && s > sScore[sy + 1][sx - 1] &&
-                           s > sScore[sy + 1][sx] && s > sScore[sy + 1][sx + 1];
+                    // strictly greater than all eight == greater than their maximum (three v_max3 + one v_max)
+                    const int n0 = max(max((int)sScore[sy - 1][sx - 1], (int)sScore[sy - 1][sx]), (int)sScore[sy - 1][sx + 1]);
+                    const int n1 = max(max((int)sScore[sy][sx - 1], (int)sScore[sy][sx + 1]), (int)sScore[sy + 1][sx - 1]);
+                    const int n2 = max((int)sScore[sy + 1][sx], (int)sScore[sy + 1][sx + 1]);
+                    keep = s > max(max(n0, n1), n2);
                 }
             }
             const unsigned long long mPre = __ballot(pre);
