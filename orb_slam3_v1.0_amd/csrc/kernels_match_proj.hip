@@ -339,13 +339,12 @@ __device__ __forceinline__ int topk_scan(const ProjArgs& A, const MpWindow& w, c
             if (dist >= A.dCut) continue;  // cannot change the verdict (proj_dcut)
             total++;
             uint32_t key = make_key32(dist, q.x);
-            if (key < keys[kTopK - 1]) {  // sorted insert
+            if (key < keys[kTopK - 1]) {
+                // sorted insert without a dependency chain: after the insert, slot t holds the median of
+                // (old keys[t-1], key, old keys[t]) -- one v_med3_u32 per slot, all 24 independent (top-down, in place)
 #pragma unroll
-                for (int t = 0; t < kTopK; t++) {
-                    const uint32_t lo = min(key, keys[t]);
-                    key = max(key, keys[t]);
-                    keys[t] = lo;
-                }
+                for (int t = kTopK - 1; t > 0; t--) keys[t] = umed3(keys[t - 1], key, keys[t]);
+                keys[0] = min(keys[0], key);
             }
         }
     }

@@ -104,6 +104,9 @@ __device__ __forceinline__ void window_cells(const GridDesc& g, MpWindow& w)
     if (w.minCX >= g.cols || w.maxCX < 0 || w.minCY >= g.rows || w.maxCY < 0) w.valid = false;
 }
 
+// median of three (v_med3_u32)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
 __device__ __forceinline__ uint32_t make_key32(int dist, int rank) { return ((uint32_t)dist << kRankBits) | (uint32_t)rank; }
 
 // host side (kernels_match_proj.hip)
