@@ -184,11 +184,11 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     // src/ORBextractor.cc:126-147); lane 31/63 (u == 16) is idle, and row 0 belongs to the upper half only
     const int au = abs(u);
     const int vmax = au <= kHalfPatch ? c_umax[au] : -1;
-    const int vmin = sgn < 0 ? 1 : 0;
-    int sumv = 0, m01 = 0;
+    // row 0 (upper half only) contributes to the column sum but not to m01; rows >= 1 need the disc test alone
+    int sumv = (sgn > 0 && vmax >= 0) ? vals[0] : 0, m01 = 0;
 #pragma unroll
-    for (int v = 0; v <= kHalfPatch; v++) {
-        const int val = (v <= vmax && v >= vmin) ? vals[v] : 0;
+    for (int v = 1; v <= kHalfPatch; v++) {
+        const int val = v <= vmax ? vals[v] : 0;
         sumv += val;
         m01 += v * val;
     }
