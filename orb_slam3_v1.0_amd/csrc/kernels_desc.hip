@@ -153,14 +153,19 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     const bool staged = inner && xs + 4 * kPatchDw <= bpitch;  // the blurred levels live in the workspace: 64-B aligned rows
     uint32_t stg[kStageIters];
     if (staged) {
-        const uint8_t* prow = blur + (y - 19) * bpitch + xs;
+        // 32-bit unsigned offsets from the (wave-uniform) level base: rows and pitches are < 2^24 and a level is < 2^32
+        // bytes, so the 24-bit multiply is exact and the loads take the scalar-base + 32-bit-offset form (no 64-bit
+        // address arithmetic)
 #pragma unroll
         for (int it = 0; it < kStageIters; it++) {
             const int e = it * 64 + lane;
-            const int r = (e * 43691) >> 19;            // e / 12 for e < 512
+            const int r = (int)(__umul24((unsigned)e, 43691u) >> 19);  // e / 12 for e < 512
             const int d = e - r * kPatchDw;
             stg[it] = 0;
-            if (e < kPatchRows * kPatchDw) stg[it] = *reinterpret_cast<const uint32_t*>(prow + r * bpitch + 4 * d);
+            if (e < kPatchRows * kPatchDw) {
+                const uint32_t off = __umul24((unsigned)(y - 19 + r), (unsigned)bpitch) + (unsigned)(xs + 4 * d);
+                stg[it] = *reinterpret_cast<const uint32_t*>(blur + off);
+            }
         }
     }
 
@@ -169,10 +174,13 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     const int sgn = (lane < 32) ? 1 : -1;
     int vals[kHalfPatch + 1];
     if (inner) {
-        const uint8_t* pcol = img + (size_t)y * ipitch + (x + u);
-        const ptrdiff_t step = (ptrdiff_t)sgn * ipitch;
+        uint32_t idx = __umul24((unsigned)y, (unsigned)ipitch) + (unsigned)(x + u);  // byte offset inside the level
+        const uint32_t step = (uint32_t)(sgn * ipitch);                             // +-pitch, modulo 2^32
 #pragma unroll
-        for (int v = 0; v <= kHalfPatch; v++) vals[v] = pcol[v * step];  // 16 independent loads in flight
+        for (int v = 0; v <= kHalfPatch; v++) {  // 16 independent loads in flight
+            vals[v] = img[idx];
+            idx += step;
+        }
     } else {
         // every level is >= 16 px and keypoints sit >= 6 px inside, so one reflection suffices
         const int cx = reflect_near(x + u, w);
