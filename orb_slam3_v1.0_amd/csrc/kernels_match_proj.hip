@@ -734,15 +734,17 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
     wave_top2_u32(k1, k2);
 }
 
-template <bool LDS>
-__global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs A)
+// THREADS: 1024 for small launches (fewest ordered chunks: shortest call); 256 when the chip is full anyway -- a 1024-thread
+// block with its register and LDS footprint keeps a whole CU to itself while it mostly waits on barriers.
+template <bool LDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
 {
     __shared__ ResolveLds S;
     __shared__ int sChanged;
     __shared__ int sCount;
     __shared__ int sFbCount;                             // starved map points of the current sweep
-    __shared__ int sFbMp[kResolveThreads];
-    __shared__ uint32_t sFbK1[kResolveThreads], sFbK2[kResolveThreads];
+    __shared__ int sFbMp[THREADS];
+    __shared__ uint32_t sFbK1[THREADS], sFbK2[THREADS];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     const int n = min(A.nKp[f], A.kpStride);
@@ -755,10 +757,10 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
 
     // claim[rank] = -1 if the slot holds a map point with observations on entry (:77-79); later the
     // smallest accepted map point (with observations) whose best match is that keypoint
-    for (int r = tid; r < n; r += kResolveThreads) claim[r] = (initObs && initObs[order[r]] > 0) ? -1 : kClaimFree;
+    for (int r = tid; r < n; r += THREADS) claim[r] = (initObs && initObs[order[r]] > 0) ? -1 : kClaimFree;
     const uint8_t* octByRank = A.octByRank + (size_t)f * A.kpStride;
     if constexpr (LDS) {
-        for (int r = tid; r < n; r += kResolveThreads) {
+        for (int r = tid; r < n; r += THREADS) {
             S.rec[r] = rec[r];
             S.oct[r] = octByRank[r];
         }
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
     if (tid == 0) sCount = 0;
     int nAccepted = 0;
 
-    for (int chunk = 0; chunk < M; chunk += kResolveThreads) {
+    for (int chunk = 0; chunk < M; chunk += THREADS) {
         const int i = chunk + tid;
         const bool live = i < M;
         int c = 0, obs = 0;
@@ -786,10 +788,10 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
             }
         }
         int res = -1;  // rank of the accepted keypoint
-        for (int iter = 0; iter <= kResolveThreads + 1; iter++) {
+        for (int iter = 0; iter <= THREADS + 1; iter++) {
             __syncthreads();
             // drop the tentative claims of this chunk (entries >= chunk), keep earlier chunks' final ones
-            for (int k = tid; k < n; k += kResolveThreads)
+            for (int k = tid; k < n; k += THREADS)
                 if (claim[k] >= chunk) claim[k] = kClaimFree;
             if (tid == 0) { sChanged = 0; sFbCount = 0; }
             __syncthreads();
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(kResolveThreads) void proj_resolve_kernel(ProjArgs 
             {
                 const int nFb = sFbCount;  // block-uniform
                 if (nFb > 0) {
-                    for (int q = tid >> 6; q < nFb; q += kResolveThreads / 64) {  // one wave per starved map point
+                    for (int q = tid >> 6; q < nFb; q += THREADS / 64) {  // one wave per starved map point
                         uint32_t a1, a2;
                         full_scan_top2_wave<LDS>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
                         if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
@@ -978,10 +980,14 @@ int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
         else
             hipLaunchKernelGGL(proj_topk_wave_kernel<false>, grid, dim3(256), 0, s, A, mpw);
     }
-    if (A.kpStride <= kResN)  // nKp[f] <= kpStride: the whole frame fits the LDS image
-        hipLaunchKernelGGL(proj_resolve_kernel<true>, dim3(A.B), dim3(kResolveThreads), 0, s, A);
-    else
-        hipLaunchKernelGGL(proj_resolve_kernel<false>, dim3(A.B), dim3(kResolveThreads), 0, s, A);
+    const bool lds = A.kpStride <= kResN;  // nKp[f] <= kpStride: the whole frame fits the LDS image
+    if (A.B >= 128) {
+        if (lds) hipLaunchKernelGGL((proj_resolve_kernel<true, 256>), dim3(A.B), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((proj_resolve_kernel<false, 256>), dim3(A.B), dim3(256), 0, s, A);
+    } else {
+        if (lds) hipLaunchKernelGGL((proj_resolve_kernel<true, kResolveThreads>), dim3(A.B), dim3(kResolveThreads), 0, s, A);
+        else hipLaunchKernelGGL((proj_resolve_kernel<false, kResolveThreads>), dim3(A.B), dim3(kResolveThreads), 0, s, A);
+    }
     MCHK(hipGetLastError());
     return ORBFE_OK;
 }

@@ -58,7 +58,7 @@ def test_projection_adversarial_claim_chain(built):
     assert n == n_ref and np.array_equal(out, out_ref)
 
 
-@pytest.mark.parametrize("B,M", [(3, 800), (24, 1500)])  # small launch: wave-per-map-point top-K; large: thread-per-map-point
+@pytest.mark.parametrize("B,M", [(3, 800), (24, 1500), (130, 700)])  # small launch: wave top-K + 1024-thread resolve; large: thread top-K; >= 128 frames: 256-thread resolve
 def test_projection_batch_device_equals_host_api(built, B, M):
     import torch
     orbfe, ex, e, kp0, desc0 = _setup()
