@@ -70,12 +70,16 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
             // addressed by the tables.
             constexpr int kPass = KPASS;
             const bool cok = c4l < ndw;
-            const uint8_t* p0 = s + (size_t)(sy0 + rl) * spitch + sx0 + 4 * c4l;
+            // 32-bit offsets from the block-uniform frame base (rows, pitches < 2^24; a level < 2^32 bytes): the loads
+            // take the scalar-base + 32-bit-offset form instead of 64-bit address arithmetic per load
+            uint32_t off = __umul24((unsigned)(sy0 + rl), (unsigned)spitch) + (unsigned)(sx0 + 4 * c4l);
+            const uint32_t step = 4u * (unsigned)spitch;
             uint32_t wv[kPass];
 #pragma unroll
             for (int k = 0; k < kPass; k++) {
                 wv[k] = 0;
-                if (cok && rl + 4 * k < nrows) wv[k] = *reinterpret_cast<const uint32_t*>(p0 + (size_t)(4 * k) * spitch);
+                if (cok && rl + 4 * k < nrows) wv[k] = *reinterpret_cast<const uint32_t*>(s + off);
+                off += step;
             }
 #pragma unroll
             for (int k = 0; k < kPass; k++)
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
                 const uint32_t v = __umul24(top, wyc) + __umul24(bot, wy) + (1u << 21);
                 outw |= (v >> 22) << (8 * i);
             }
-            uint8_t* d = dst + (size_t)f * dstFrameStride + (size_t)y * dpitch;
+            uint8_t* d = dst + (size_t)f * dstFrameStride + __umul24((unsigned)y, (unsigned)dpitch);
             if (nvalid == 4) {
                 *reinterpret_cast<uint32_t*>(d + x0) = outw;  // dpitch % 64 == 0 and x0 % 4 == 0
             } else {
