@@ -20,10 +20,10 @@
 //
 // Tile: 64 x 32 pixels per 256-thread block; the level tile + 4-px halo (3 ring + 1 NMS; the blur
 // needs 2) is staged ONCE in LDS with dword loads and feeds both computations.
-// The per-pixel FAST work is split into three stages of rising cost and falling population
-// (compass test -> full segment test -> corner score) with LDS queues between them, so each stage
-// runs on a dense set of lanes: with ~6 % of pixels being corners a monolithic per-pixel function
-// makes nearly every 64-lane wave pay for the most expensive path.
+// The per-pixel FAST work is split into stages of rising cost and falling population (compass test ->
+// segment test + corner score in one -> NMS) with LDS queues between them, so each stage runs on a dense
+// set of lanes: with ~6 % of pixels being corners a monolithic per-pixel function makes nearly every
+// 64-lane wave pay for the most expensive path.
 // Candidate order in HBM is not deterministic (one atomicAdd per block reserves the slots) -- every
 // consumer is order-independent: it uses the raster key (y, x) carried in the word (S2b).
 // Algorithmic bytes per pixel: 1 read (level) + 1 written (blurred level) + 4 per candidate.
@@ -57,6 +57,35 @@ __device__ __forceinline__ int arc_max_min(const int (&a)[16])
     return max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), g[5]));
 }
 
+// min over the 16 circular 9-arcs of the maximum of a[] over the arc (the dark polarity's mirror image)
+__device__ __forceinline__ int arc_min_max(const int (&a)[16])
+{
+    int t[16], m9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[k] = max(max(a[k], a[(k + 1) & 15]), a[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m9[k] = max(max(t[k], t[(k + 3) & 15]), t[(k + 6) & 15]);
+    int g[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) g[k] = min(min(m9[3 * k], m9[3 * k + 1]), m9[3 * k + 2]);
+    g[5] = m9[15];
+    return min(min(min(g[0], g[1]), g[2]), min(min(g[3], g[4]), g[5]));
+}
+
+// Stages B + C in one: on the RAW ring values, hi = (max over 9-arcs of the arc minimum) - v and
+// lo = v - (min over 9-arcs of the arc maximum) are the largest margins by which a bright / dark 9-arc clears the
+// centre.  The pixel is a corner at threshold th iff max(hi, lo) > th (the segment test of Fast_gpu.cu:222-267), and
+// max(hi, lo) - 1 is the score the reference finds by binary search (:193-216).  80 three-input min / max instead of
+// two 16-bit ring masks (64 compare / shift-in + two 9-run tests) -- the same cost -- and no separate score pass.
+__device__ __forceinline__ int corner_margin(const uint8_t (*img)[kImgW], int r, int c)
+{
+    const int v = img[r][c];
+    const int p[16] = {img[r + 3][c],     img[r + 3][c + 1], img[r + 2][c + 2], img[r + 1][c + 3], img[r][c + 3],     img[r - 1][c + 3],
+                       img[r - 2][c + 2], img[r - 3][c + 1], img[r - 3][c],     img[r - 3][c - 1], img[r - 2][c - 2], img[r - 1][c - 3],
+                       img[r][c - 3],     img[r + 1][c - 3], img[r + 2][c - 2], img[r + 3][c - 1]};
+    return max(arc_max_min(p) - v, v - arc_min_max(p));
+}
+
 // stage A: compass points = ring bits 0 (+3,0), 4 (0,+3), 8 (-3,0), 12 (0,-3).  Nine consecutive
 // ring positions always contain two ADJACENT compass points (consecutive multiples of 4), so a
 // corner needs an adjacent compass pair that is bright (both > th) or dark (both < -th).
@@ -70,62 +99,6 @@ __device__ __forceinline__ bool compass_pass_ptr(const uint8_t* p, int th)
     const int hiPair = min(max(a0, a8), max(a4, a12));  // thresholds move to the centre value: no per-point subtraction
     const int loPair = max(min(a0, a8), min(a4, a12));
     return hiPair > v + th || loPair < v - th;
-}
-
-__device__ __forceinline__ void ring_diffs(const uint8_t (*img)[kImgW], int r, int c, int (&d)[16])
-{
-    const int v = img[r][c];
-    d[0] = img[r + 3][c] - v;      d[1] = img[r + 3][c + 1] - v;  d[2] = img[r + 2][c + 2] - v;
-    d[3] = img[r + 1][c + 3] - v;  d[4] = img[r][c + 3] - v;      d[5] = img[r - 1][c + 3] - v;
-    d[6] = img[r - 2][c + 2] - v;  d[7] = img[r - 3][c + 1] - v;  d[8] = img[r - 3][c] - v;
-    d[9] = img[r - 3][c - 1] - v;  d[10] = img[r - 2][c - 2] - v; d[11] = img[r - 1][c - 3] - v;
-    d[12] = img[r][c - 3] - v;     d[13] = img[r + 1][c - 3] - v; d[14] = img[r + 2][c - 2] - v;
-    d[15] = img[r + 3][c - 1] - v;
-}
-
-// m = 2 * m + (a > b): the compare lands in VCC and v_addc shifts it in -- two instructions per ring bit
-// instead of compare + select + shift-or (the compiler has no pattern for this)
-__device__ __forceinline__ void shift_in_gt(uint32_t& m, int a, int b)
-{
-    asm("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
-}
-
-// stage B: full 16-pixel segment test at threshold th; bit 0 = bright 9-arc, bit 1 = dark 9-arc.
-// The ring masks are built most-significant-bit first (ring position 0 ends up in bit 15): a reversed
-// ring is still a ring, so the circular 9-run test is unchanged.
-__device__ __forceinline__ uint32_t segment_test(const uint8_t (*img)[kImgW], int r, int c, int th)
-{
-    const int v = img[r][c];
-    const int hiT = v + th, loT = v - th;
-    const int p[16] = {img[r + 3][c],     img[r + 3][c + 1], img[r + 2][c + 2], img[r + 1][c + 3], img[r][c + 3],     img[r - 1][c + 3],
-                       img[r - 2][c + 2], img[r - 3][c + 1], img[r - 3][c],     img[r - 3][c - 1], img[r - 2][c - 2], img[r - 1][c - 3],
-                       img[r][c - 3],     img[r + 1][c - 3], img[r + 2][c - 2], img[r + 3][c - 1]};
-    uint32_t mb = 0, md = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        shift_in_gt(mb, p[k], hiT);  // p - v > th
-        shift_in_gt(md, loT, p[k]);  // p - v < -th
-    }
-    return (uint32_t)arc9(mb) | ((uint32_t)arc9(md) << 1);
-}
-
-// stage C: largest t such that some 9-arc has all |diff| > t  ==  max-min over arcs, minus 1
-// (equals the binary search of cornerScore, Fast_gpu.cu:193-216).  A polarity without a 9-arc at
-// `th` has max-min <= th < the other polarity's, so only polarities that pass arc9 are evaluated
-// (both pass only for exotic rings).
-__device__ __forceinline__ int corner_score(const int (&d)[16], bool pb, bool pd)
-{
-    const int sgn = pb ? 1 : -1;
-    int a[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = __mul24(sgn, d[k]);  // |d| <= 255: the 24-bit multiply is full rate
-    int best = arc_max_min(a);
-    if (pb && pd) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) a[k] = -d[k];
-        best = max(best, arc_max_min(a));
-    }
-    return best - 1;
 }
 
 // append `flag`ged lanes' value to an LDS queue (one LDS atomic per wave)
@@ -156,7 +129,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     __shared__ uint32_t sCand[kMaxTileCand];
     __shared__ uint32_t sCnt[4];  // tile: survivors, high survivors, pre-NMS low, pre-NMS high
     __shared__ uint32_t sBase;
-    __shared__ uint16_t sQA[kScH * kScW];  // stage queues; entry = sy << 7 | sx (score-map position), queue B adds the polarity in bits 13, 14
+    __shared__ uint16_t sQA[kScH * kScW];  // stage queues; entry = sy << 7 | sx (score-map position)
     __shared__ uint16_t sQB[kScH * kScW];
     __shared__ uint32_t sQ[2];
 
@@ -381,36 +354,28 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         }
     }
     __syncthreads();
-    // stage B: full segment test on queue A (dense), corners -> queue B
+    // stage B: corner margin on queue A (dense); corners -> score map + queue B
     if constexpr ((MODE & 4) == 0) {
         const int nA = (int)sQ[0];
         const int itB = (nA + 255) / 256;
 #pragma unroll 1
         for (int it = 0; it < itB; it++) {
             const int i = tid + it * 256;
-            uint32_t pol = 0;
+            bool corner = false;
             uint16_t e = 0;
             if (i < nA) {
                 e = sQA[i];
                 const int sy = e >> 7;
                 const int sx = e & 127;
-                pol = segment_test(sImg, sy + 3, sx + 3, minTh);
+                const int margin = corner_margin(sImg, sy + 3, sx + 3);
+                corner = margin > minTh;
+                if (corner) sScore[sy][sx] = (uint8_t)(margin - 1);
             }
-            queue_push(pol != 0, (uint16_t)(e | (pol << 13)), sQB, &sQ[1], lane);  // e < 2^13
+            queue_push(corner, e, sQB, &sQ[1], lane);
         }
     }
     __syncthreads();
-    // stage C: corner score on queue B (dense)
     const int nB = (MODE & 8) ? 0 : (int)sQ[1];
-    for (int i = tid; i < nB; i += 256) {
-        const uint32_t q = sQB[i];
-        const int sy = (int)((q >> 7) & 63u);
-        const int sx = (int)(q & 127u);
-        int d[16];
-        ring_diffs(sImg, sy + 3, sx + 3, d);
-        sScore[sy][sx] = (uint8_t)corner_score(d, (q & 0x2000u) != 0, (q & 0x4000u) != 0);
-    }
-    __syncthreads();
 
     // ---- NMS (strictly greater than all 8 neighbours, Fast_gpu.cu:300-310) + tile compaction,
     //      again over the dense corner queue; halo corners only serve as neighbours ----
