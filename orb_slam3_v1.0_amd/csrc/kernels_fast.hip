@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     __shared__ uint32_t sCnt[4];  // tile: survivors, high survivors, pre-NMS low, pre-NMS high
     __shared__ uint32_t sBase;
     __shared__ uint16_t sQA[kScH * kScW];  // stage queues; entry = sy << 7 | sx (score-map position)
-    __shared__ uint16_t sQB[kScH * kScW];
+    // queue B lives in the Gaussian's row-pair buffer: sTmp is dead once the vertical pass has run, and a barrier
+    // (after stage A) separates its last read from the first queue-B write -- 4.4 KB less LDS: 8 blocks per CU instead of 7
+    static_assert(sizeof(uint16_t) * kScH * kScW <= sizeof(uint32_t) * (kTmpH / 2) * kFastTW, "queue B must fit the blur buffer");
+    uint16_t* const sQB = reinterpret_cast<uint16_t*>(&sTmp[0][0]);
     __shared__ uint32_t sQ[2];
 
     const int f = blockIdx.x;
