@@ -153,18 +153,23 @@ __global__ __launch_bounds__(256) void orient_brief_kernel(const PipelineDesc* _
     const bool staged = inner && xs + 4 * kPatchDw <= bpitch;  // the blurred levels live in the workspace: 64-B aligned rows
     uint32_t stg[kStageIters];
     if (staged) {
-        // 32-bit unsigned offsets from the (wave-uniform) level base: rows and pitches are < 2^24 and a level is < 2^32
-        // bytes, so the 24-bit multiply is exact and the loads take the scalar-base + 32-bit-offset form (no 64-bit
-        // address arithmetic)
+        // 32-bit unsigned offsets from the (wave-uniform) level base (rows and pitches are < 2^24, a level is < 2^32
+        // bytes): scalar-base + 32-bit-offset loads, no 64-bit address arithmetic.  Element e = it * 64 + lane of the
+        // 39 x 12 dword window sits at (row e / 12, dword e % 12); e + 64 is five rows and four dwords further, so the
+        // (row, dword) pair and the offset advance incrementally instead of a division per iteration.
+        int r = (int)(__umul24((unsigned)lane, 43691u) >> 19);  // lane / 12
+        int d = lane - r * kPatchDw;
+        uint32_t off = __umul24((unsigned)(y - 19 + r), (unsigned)bpitch) + (unsigned)(xs + 4 * d);
+        const uint32_t rowStep = 5u * (unsigned)bpitch + 16u, wrapStep = (unsigned)bpitch - 48u;
 #pragma unroll
         for (int it = 0; it < kStageIters; it++) {
-            const int e = it * 64 + lane;
-            const int r = (int)(__umul24((unsigned)e, 43691u) >> 19);  // e / 12 for e < 512
-            const int d = e - r * kPatchDw;
             stg[it] = 0;
-            if (e < kPatchRows * kPatchDw) {
-                const uint32_t off = __umul24((unsigned)(y - 19 + r), (unsigned)bpitch) + (unsigned)(xs + 4 * d);
-                stg[it] = *reinterpret_cast<const uint32_t*>(blur + off);
+            if (it * 64 + lane < kPatchRows * kPatchDw) stg[it] = *reinterpret_cast<const uint32_t*>(blur + off);
+            d += 4;
+            off += rowStep;
+            if (d >= kPatchDw) {
+                d -= kPatchDw;
+                off += wrapStep;
             }
         }
     }
