@@ -30,3 +30,14 @@ g1 = orbfe.make_frame_view(k1, d1, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvSc
 g2 = orbfe.make_frame_view(k2, d2, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
 for _ in range(300):
     m.SearchForInitialization(g1, g2, 100, 0.9, True)
+import test_triangulation  # noqa: E402
+import numpy as np  # noqa: E402
+kf_off, kf_idx, f_off, f_idx, has = S.bow_scenario(k1, d1, k2, d2, 100, 3)
+for _ in range(300):
+    m.SearchByBoW(kf_off, kf_idx, f_off, f_idx, d1, k1["angle"], has, d2, k2["angle"], 0.75, True)
+off1, idx1, off2, idx2, kpt2, dt2, h1, h2, s1_, s2_, F12, ep = test_triangulation.scenario(k1.view(O.KP_DTYPE), d1, 2, True, False)
+off1, idx1, off2, idx2 = (np.asarray(x, np.int32) for x in (off1, idx1, off2, idx2))
+h1, h2 = h1.astype(np.uint8), h2.astype(np.uint8)
+for _ in range(300):
+    m.SearchForTriangulation(off1, idx1, off2, idx2, k1, d1, h1, None, kpt2.view(orbfe.KP_DTYPE), dt2, h2, None, ex.mvScaleFactor, F12, ep,
+                             False, False, True)
