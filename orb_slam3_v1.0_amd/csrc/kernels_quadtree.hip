@@ -59,12 +59,16 @@ __device__ __forceinline__ Box child_box(const Box& b, int c)
 __device__ __forceinline__ int block_excl_scan(int v, int& total, int* sWave)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave-level inclusive scan with DPP row shifts (one VALU instruction per step; the LDS permute of __shfl_up costs
+    // a round trip per step and this kernel is a chain of scans): Hillis-Steele inside the 16-lane rows, then the row
+    // totals ripple through row_bcast 15 / 31.  Shifted-in and masked-off lanes read 0.
     int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, true);  // row_bcast:15 into rows 1 and 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, true);  // row_bcast:31 into rows 2 and 3
     __syncthreads();  // protect sWave from the previous use
     if (lane == 63) sWave[wave] = incl;
     __syncthreads();
