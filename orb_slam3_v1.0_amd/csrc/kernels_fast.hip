@@ -108,7 +108,7 @@ __device__ __forceinline__ void queue_push(bool flag, uint16_t value, uint16_t* 
     if (m == 0) return;  // wave-uniform
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(qCount, (uint32_t)__popcll(m));
-    base = __shfl(base, 0);
+    base = __builtin_amdgcn_readfirstlane(base);  // lane 0 is active: every thread of the block calls this
     if (flag) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                 if (mKeepHi) atomicAdd(&sCnt[1], (uint32_t)__popcll(mKeepHi));
                 if (mKeep) wbase = atomicAdd(&sCnt[0], (uint32_t)__popcll(mKeep));
             }
-            wbase = __shfl(wbase, 0);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
             if (keep) {
                 const uint32_t rank = (uint32_t)__popcll(mKeep & ((1ull << lane) - 1ull));
                 sCand[wbase + rank] = pack_cand(x0 + ox, y0 + oy, s);
