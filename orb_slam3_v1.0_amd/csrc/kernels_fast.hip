@@ -182,12 +182,25 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             const int gx = x0 - 4 + 4 * c4;
             const bool colIn = gx >= 0 && gx < w;
             uint32_t wv[3];
+            // tiles whose 40 staged rows lie inside the level (block-uniform; all but the first and last tile rows) need
+            // no reflection: 32-bit offsets from the uniform level base, one add per row
+            if (y0 >= 4 && y0 + kFastTH + 4 <= h) {
+                uint32_t off = __umul24((unsigned)(y0 - 4 + r0), (unsigned)spitch) + (unsigned)gx;
+                const uint32_t step = 14u * (unsigned)spitch;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int r = r0 + 14 * k;
-                wv[k] = 0;
-                if (colIn && r < kImgH)
-                    wv[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect_near(y0 - 4 + r, h) * spitch + gx);
+                for (int k = 0; k < 3; k++) {
+                    wv[k] = 0;
+                    if (colIn && r0 + 14 * k < kImgH) wv[k] = *reinterpret_cast<const uint32_t*>(src + off);
+                    off += step;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int r = r0 + 14 * k;
+                    wv[k] = 0;
+                    if (colIn && r < kImgH)
+                        wv[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)reflect_near(y0 - 4 + r, h) * spitch + gx);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
