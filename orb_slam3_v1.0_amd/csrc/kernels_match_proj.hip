@@ -767,6 +767,7 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
     }
     if (tid == 0) sCount = 0;
     int nAccepted = 0;
+    __syncthreads();  // claim table and LDS image complete before the first sweep
 
     for (int chunk = 0; chunk < M; chunk += THREADS) {
         const int i = chunk + tid;
@@ -789,12 +790,13 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
         }
         int res = -1;  // rank of the accepted keypoint
         for (int iter = 0; iter <= THREADS + 1; iter++) {
-            __syncthreads();
+            // (the barrier that ends the previous sweep -- or the one before the chunk loop -- orders this sweep's claim
+            // edits after every earlier read of the table)
             // drop the tentative claims of this chunk (entries >= chunk), keep earlier chunks' final ones
             for (int k = tid; k < n; k += THREADS)
                 if (claim[k] >= chunk) claim[k] = kClaimFree;
-            if (tid == 0) { sChanged = 0; sFbCount = 0; }
             __syncthreads();
+            if (tid == 0) { sChanged = 0; sFbCount = 0; }  // every thread has read the previous sweep's sChanged by now
             if (res >= 0 && obs > 0) atomicMin(&claim[res], i);
             __syncthreads();
             int result = -1;
