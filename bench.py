@@ -159,6 +159,7 @@ def main():
                     help="run the RCCL result gather even at N=1 (a 1-rank process group): exercises the N>1 code path on one GPU")
     ap.add_argument("--no-match", action="store_true", help="extract only")
     ap.add_argument("--no-overlap", action="store_true", help="match on the extraction stream (no 2-stream pipelining)")
+    ap.add_argument("--lib", default=None, help="load this build of liborbfe instead (tools/: the timing-only ablation build)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,6 +184,8 @@ def main():
 
     import orbfe
     from orbfe import synth
+    if a.lib:
+        orbfe.LIB_PATH = os.path.abspath(a.lib)
 
     cfg = WORKLOADS[a.workload]
     W, H = cfg[6], cfg[7]

@@ -20,10 +20,17 @@
 //
 // Tile: 64 x 32 pixels per 256-thread block; the level tile + 4-px halo (3 ring + 1 NMS; the blur
 // needs 2) is staged ONCE in LDS with dword loads and feeds both computations.
-// The per-pixel FAST work is split into stages of rising cost and falling population (compass test ->
-// segment test + corner score in one -> NMS) with LDS queues between them, so each stage runs on a dense
-// set of lanes: with ~6 % of pixels being corners a monolithic per-pixel function makes nearly every
-// 64-lane wave pay for the most expensive path.
+//
+// The kernel is bound by VALU issue (tools/valu_rate.hip: the integer min / max / perm / packed-16 instructions cost
+// 4 cycles per wave64 instruction per SIMD on gfx950, and the kernel runs at ~90 % of that), so every stage is
+// written for the fewest vector instructions per pixel:
+//   stage A  compass pre-test on every position with PACKED 16-bit arithmetic: a lane owns 4 columns x 5 rows,
+//            reads the tile as dwords and unpacks column pairs with v_perm_b32, so each v_pk_min/max_u16 tests
+//            two pixels (two waves, 126 lanes); survivors (~20 % of the positions) go to an LDS queue;
+//   stage B  segment test + corner score of TWO queued pixels per lane, again packed: the sixteen 9-arcs of
+//            both polarities by prefix / suffix minima over the ring halves (57 packed instructions per polarity
+//            for two pixels instead of 40 three-input ones per pixel and polarity);
+//   stage C  NMS + compaction over the dense corner queue.
 // Candidate order in HBM is not deterministic (one atomicAdd per block reserves the slots) -- every
 // consumer is order-independent: it uses the raster key (y, x) carried in the word (S2b).
 // Algorithmic bytes per pixel: 1 read (level) + 1 written (blurred level) + 4 per candidate.
@@ -36,86 +43,147 @@
 namespace orbfe {
 
 constexpr int kImgW = kFastTW + 8, kImgH = kFastTH + 8;   // 72 x 40 staged pixels (tile size: fast_common.h)
-constexpr int kScW = kFastTW + 2, kScH = kFastTH + 2;     // 66 x 34 scores
-constexpr int kScPitch = 68;
+constexpr int kScH = kFastTH + 2;                         // 34 score rows; score columns 0..65
+constexpr int kScW = kFastTW + 2;
+// the score map uses the image's LDS pitch, so "score of the pixel staged at byte e" is one constant away
+constexpr int kScPitch = kImgW;
+constexpr int kScoreOfs = 3 * kImgW + 3;                  // score (sy, sx) <-> staged pixel (sy + 3, sx + 3)
 constexpr int kMaxTileCand = (kFastTW / 2) * (kFastTH / 2);  // strict 8-neighbour maxima: <= 1 per 2x2
 constexpr int kTmpH = kFastTH + 4;                        // 36 rows of horizontal blur sums
+// stage A geometry: 18 column groups of 4 staged columns x 7 strips of 5 score rows
+constexpr int kGroups = kImgW / 4, kStripRows = 5, kStrips = (kScH + kStripRows - 1) / kStripRows;
+constexpr int kTasks = kGroups * kStrips;                 // 126 lanes of waves 0 and 1
+constexpr int kQCap = 2304;                               // queue A slots (>= 66 * 34), even
+static_assert(kTasks <= 128 && kQCap >= kScH * kScW && kQCap % 2 == 0, "stage A geometry");
 
-// max over the 16 circular 9-arcs of the minimum of a[] over the arc.  Three-input min / max (v_min3_i32, v_max3_i32):
-// t[k] = min of 3 consecutive, arc minimum = min3(t[k], t[k+3], t[k+6]) -- 32 + 8 instructions instead of 64 + 16.
-__device__ __forceinline__ int arc_max_min(const int (&a)[16])
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u(uint32_t a, uint32_t b)
 {
-    int t[16], m9[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) t[k] = min(min(a[k], a[(k + 1) & 15]), a[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m9[k] = min(min(t[k], t[(k + 3) & 15]), t[(k + 6) & 15]);
-    int g[6];
-#pragma unroll
-    for (int k = 0; k < 5; k++) g[k] = max(max(m9[3 * k], m9[3 * k + 1]), m9[3 * k + 2]);
-    g[5] = m9[15];
-    return max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), g[5]));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (i16x2)(__builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b)));
 }
 
-// min over the 16 circular 9-arcs of the maximum of a[] over the arc (the dark polarity's mirror image)
-__device__ __forceinline__ int arc_min_max(const int (&a)[16])
+// Both corner margins of TWO pixels at once (one per 16-bit half): p[k] = ring value k of pixel A | of pixel B << 16,
+// v = their centres.  hi = (max over the sixteen 9-arcs of the arc minimum) - v and lo = v - (min over the arcs of the
+// arc maximum) are the largest margins by which a bright / dark 9-arc clears the centre; the pixel is a corner at
+// threshold th iff max(hi, lo) > th (the segment test of Fast_gpu.cu:222-267) and max(hi, lo) - 1 is the score the
+// reference finds by binary search (:193-216).  Arc k = ring positions k..k+8.  With S[k] = min(p[k..7]),
+// S'[k] = min(p[k..15]), P[k] = min(p[8..k]), P'[k] = min(p[0..k]):  arc k = min(S[k], P[k+8]) for k < 8 and
+// min(S'[k], P'[k-8]) for k >= 8 -- 26 + 16 two-input minima, 15 maxima.
+template <bool DARK>
+__device__ __forceinline__ uint32_t arc_extreme(const uint32_t (&p)[16])
 {
-    int t[16], m9[16];
+    auto inner = [](uint32_t a, uint32_t b) { return DARK ? pk_max_u(a, b) : pk_min_u(a, b); };
+    auto outer = [](uint32_t a, uint32_t b) { return DARK ? pk_min_u(a, b) : pk_max_u(a, b); };
+    uint32_t S[16], Pf[16];
+    S[7] = p[7];
+    S[15] = p[15];
 #pragma unroll
-    for (int k = 0; k < 16; k++) t[k] = max(max(a[k], a[(k + 1) & 15]), a[(k + 2) & 15]);
+    for (int k = 6; k >= 0; k--) {
+        S[k] = inner(p[k], S[k + 1]);
+        S[k + 8] = inner(p[k + 8], S[k + 9]);
+    }
+    Pf[0] = p[0];
+    Pf[8] = p[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) m9[k] = max(max(t[k], t[(k + 3) & 15]), t[(k + 6) & 15]);
-    int g[6];
+    for (int k = 1; k < 7; k++) {
+        Pf[k] = inner(p[k], Pf[k - 1]);
+        Pf[k + 8] = inner(p[k + 8], Pf[k + 7]);
+    }
+    Pf[7] = S[0];    // min of the whole half
+    Pf[15] = S[8];
+    uint32_t a[16];
 #pragma unroll
-    for (int k = 0; k < 5; k++) g[k] = min(min(m9[3 * k], m9[3 * k + 1]), m9[3 * k + 2]);
-    g[5] = m9[15];
-    return min(min(min(g[0], g[1]), g[2]), min(min(g[3], g[4]), g[5]));
+    for (int k = 0; k < 8; k++) {
+        a[k] = inner(S[k], Pf[k + 8]);
+        a[k + 8] = inner(S[k + 8], Pf[k]);
+    }
+#pragma unroll
+    for (int st = 8; st >= 1; st >>= 1)
+#pragma unroll
+        for (int k = 0; k < st; k++) a[k] = outer(a[k], a[k + st]);
+    return a[0];
 }
 
-// Stages B + C in one: on the RAW ring values, hi = (max over 9-arcs of the arc minimum) - v and
-// lo = v - (min over 9-arcs of the arc maximum) are the largest margins by which a bright / dark 9-arc clears the
-// centre.  The pixel is a corner at threshold th iff max(hi, lo) > th (the segment test of Fast_gpu.cu:222-267), and
-// max(hi, lo) - 1 is the score the reference finds by binary search (:193-216).  80 three-input min / max instead of
-// two 16-bit ring masks (64 compare / shift-in + two 9-run tests) -- the same cost -- and no separate score pass.
-__device__ __forceinline__ int corner_margin(const uint8_t (*img)[kImgW], int r, int c)
+
+// lane mask of (unsigned)x <= bound / of a > b, straight from the compare (a ballot of a combined predicate costs hipcc a
+// v_cndmask + v_cmp pair)
+__device__ __forceinline__ unsigned long long mask_le_u32(uint32_t x, uint32_t bound)
 {
-    const int v = img[r][c];
-    const int p[16] = {img[r + 3][c],     img[r + 3][c + 1], img[r + 2][c + 2], img[r + 1][c + 3], img[r][c + 3],     img[r - 1][c + 3],
-                       img[r - 2][c + 2], img[r - 3][c + 1], img[r - 3][c],     img[r - 3][c - 1], img[r - 2][c - 2], img[r - 1][c - 3],
-                       img[r][c - 3],     img[r + 1][c - 3], img[r + 2][c - 2], img[r + 3][c - 1]};
-    return max(arc_max_min(p) - v, v - arc_min_max(p));
+    unsigned long long m;
+    asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "s"(bound));
+    return m;
 }
 
-// stage A: compass points = ring bits 0 (+3,0), 4 (0,+3), 8 (-3,0), 12 (0,-3).  Nine consecutive
-// ring positions always contain two ADJACENT compass points (consecutive multiples of 4), so a
-// corner needs an adjacent compass pair that is bright (both > th) or dark (both < -th).
-// `p` points at the centre pixel inside the staged tile (row pitch kImgW).
-__device__ __forceinline__ bool compass_pass_ptr(const uint8_t* p, int th)
+// LDS fetch-add issued by the calling lane(s) as written (hipcc's atomic optimizer wraps a single-lane atomicAdd in a
+// wave reduction)
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* addr, uint32_t v)
 {
-    // the compass cycle 0-4-8-12 is bipartite ({0,8} vs {4,12}) and every cross pair is adjacent, so
-    // "some adjacent pair is bright" == (0 or 8 bright) and (4 or 12 bright); same for dark
-    const int v = p[0];
-    const int a0 = p[3 * kImgW], a4 = p[3], a8 = p[-3 * kImgW], a12 = p[-3];
-    const int hiPair = min(max(a0, a8), max(a4, a12));  // thresholds move to the centre value: no per-point subtraction
-    const int loPair = max(min(a0, a8), min(a4, a12));
-    return hiPair > v + th || loPair < v - th;
+    uint32_t old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"((uint32_t)(uintptr_t)addr), "v"(v) : "memory");
+    return old;
 }
 
-// append `flag`ged lanes' value to an LDS queue (one LDS atomic per wave)
-__device__ __forceinline__ void queue_push(bool flag, uint16_t value, uint16_t* q, uint32_t* qCount, int lane)
+// One compaction step of stage A, hand-scheduled (hipcc turns the same source into 9 vector instructions per step:
+// it rebuilds the ballot through v_cndmask + v_cmp and masks the 16-bit half before comparing it).  The lanes whose
+// 16-bit half of d (HIGH: bits 31..16) is negative and that are valid in both lane masks append `entry` to the queue
+// at byte address qNext + rank * step; returns how many did.  EXEC is narrowed and restored inside the statement.
+template <bool HIGH>
+__device__ __forceinline__ int queue_slot(uint32_t d, unsigned long long colMask, unsigned long long rowMask, uint32_t entry,
+                                          int stepV, int qNext)
 {
-    const unsigned long long m = __ballot(flag);
-    if (m == 0) return;  // wave-uniform
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(qCount, (uint32_t)__popcll(m));
-    base = __builtin_amdgcn_readfirstlane(base);  // lane 0 is active: every thread of the block calls this
-    if (flag) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+    unsigned long long save;
+    uint32_t tmp;
+    int cnt;
+    if constexpr (HIGH)
+        asm volatile("v_cmp_gt_i32_e32 vcc, 0, %3\n\t"
+                     "s_and_b64 vcc, vcc, %4\n\t"
+                     "s_and_b64 vcc, vcc, %5\n\t"
+                     "s_and_saveexec_b64 %0, vcc\n\t"
+                     "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
+                     "v_mad_i32_i24 %1, %1, %7, %8\n\t"
+                     "ds_write_b16 %1, %6\n\t"
+                     "s_mov_b64 exec, %0\n\t"
+                     "s_bcnt1_i32_b64 %2, vcc"
+                     : "=&s"(save), "=&v"(tmp), "=s"(cnt)
+                     : "v"(d), "s"(colMask), "s"(rowMask), "v"(entry), "v"(stepV), "s"(qNext)
+                     : "vcc", "scc", "memory");
+    else
+        asm volatile("v_cmp_gt_i16_e32 vcc, 0, %3\n\t"
+                     "s_and_b64 vcc, vcc, %4\n\t"
+                     "s_and_b64 vcc, vcc, %5\n\t"
+                     "s_and_saveexec_b64 %0, vcc\n\t"
+                     "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
+                     "v_mad_i32_i24 %1, %1, %7, %8\n\t"
+                     "ds_write_b16 %1, %6\n\t"
+                     "s_mov_b64 exec, %0\n\t"
+                     "s_bcnt1_i32_b64 %2, vcc"
+                     : "=&s"(save), "=&v"(tmp), "=s"(cnt)
+                     : "v"(d), "s"(colMask), "s"(rowMask), "v"(entry), "v"(stepV), "s"(qNext)
+                     : "vcc", "scc", "memory");
+    return cnt;
 }
 
-// MODE is a timing-only ablation switch (ORBFE_FAST_MODE env var): bit 0 = Gaussian, bit 1 = FAST;
-// the product always runs MODE 3.
+// MODE is a timing-only ablation switch (bit 0 = Gaussian, bit 1 = FAST, bit 2 = stop after stage A, bit 3 = stop
+// after stage B); the shipped library instantiates MODE 3 only -- the other variants exist in the -DORBFE_ABLATION
+// build (`make ablation`) used by tools/fast_stage_*.sh.
 template <int MODE>
 __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __restrict__ P,
+                                                        const uint32_t* __restrict__ tileInfo,
                                                         const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
                                                         int gray0Pitch, int gray0Aligned4,
                                                         uint8_t* __restrict__ ws, uint32_t* __restrict__ cand,
@@ -123,32 +191,31 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                                                         uint32_t* __restrict__ tileRows)
 {
     __shared__ uint32_t sRow[kFastTH];  // pre-NMS corners per tile row: low-pass count | high-pass count << 16
-    __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH][kImgW];
+    __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH + 1][kImgW];  // + 1 row: stage A reads row 40 for positions it masks
     __shared__ __attribute__((aligned(16))) uint32_t sTmp[kTmpH / 2][kFastTW];  // row pairs of horizontal sums
-    __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH][kScPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH + 1][kScPitch];
     __shared__ uint32_t sCand[kMaxTileCand];
     __shared__ uint32_t sCnt[4];  // tile: survivors, high survivors, pre-NMS low, pre-NMS high
     __shared__ uint32_t sBase;
-    __shared__ uint16_t sQA[kScH * kScW];  // stage queues; entry = sy << 7 | sx (score-map position)
-    // queue B lives in the Gaussian's row-pair buffer: sTmp is dead once the vertical pass has run, and a barrier
-    // (after stage A) separates its last read from the first queue-B write -- 4.4 KB less LDS: 8 blocks per CU instead of 7
-    static_assert(sizeof(uint16_t) * kScH * kScW <= sizeof(uint32_t) * (kTmpH / 2) * kFastTW, "queue B must fit the blur buffer");
+    // queue A: staged-pixel byte offsets (r * 72 + c) of the positions that pass the compass test; wave 0 fills it
+    // from slot 0 upwards, wave 1 from the last slot downwards (no reservation, no atomics)
+    __shared__ __attribute__((aligned(4))) uint16_t sQA[kQCap];
+    // the corner queue lives in the Gaussian's row-pair buffer: sTmp is dead once the vertical pass has run, and a
+    // barrier (after stage A) separates its last read from the first corner-queue write
+    static_assert(sizeof(uint16_t) * kScH * kScW <= sizeof(uint32_t) * (kTmpH / 2) * kFastTW, "corner queue must fit the blur buffer");
     uint16_t* const sQB = reinterpret_cast<uint16_t*>(&sTmp[0][0]);
-    __shared__ uint32_t sQ[2];
+    __shared__ uint32_t sQ[3];  // entries of queue A by wave 0 / wave 1, corner-queue entries
 
     const int f = blockIdx.x;
     const int tile = blockIdx.y;
     const int nL = P->nLevels;
-    // tile -> level without a chain of dependent scalar loads: the first 8 bases arrive in one load
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < 8; i++) l = tile >= P->tileBaseTab[i] ? i : l;
-    while (l + 1 < nL && tile >= P->lv[l + 1].tileBase) l++;  // levels >= 8 (rare)
+    // tile -> (level, tile column, tile row) from one scalar load (host table, orbfe_create)
+    const uint32_t ti = tileInfo[tile];
+    const int l = (int)(ti >> 24);
     const LevelDesc& L = P->lv[l];
     const int w = L.w, h = L.h;
-    const int t = tile - L.tileBase;
-    const int x0 = (t % L.tilesX) * kFastTW;
-    const int y0 = (t / L.tilesX) * kFastTH;
+    const int x0 = (int)(ti & 0xfffu) * kFastTW;
+    const int y0 = (int)((ti >> 12) & 0xfffu) * kFastTH;
     const int minTh = P->minTh, iniTh = P->iniTh;
 
     const uint8_t* src;
@@ -167,7 +234,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     if (tid < 4) sCnt[tid] = 0;
-    if (tid < 2) sQ[tid] = 0;
+    if (tid < 3) sQ[tid] = 0;
     if (tid < kFastTH) sRow[tid] = 0;
 
     // ---- stage the 72 x 40 tile (origin x0-4, y0-4).  Thread -> fixed dword column c4 (18 per row) and
@@ -272,159 +339,224 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         *reinterpret_cast<uint4*>(&sTmp[j][xl]) = pk;
     }
     __syncthreads();
-    // vertical: thread -> 4 columns x output rows 2*yp, 2*yp+1 (tmp rows 2yp..2yp+5 = pairs yp..yp+2), one
-    // rounding (+32768 >> 16) folded into the accumulator init; the result is byte 2 of each accumulator
-    {
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        uint8_t* dst = ws + L.blurOff + (size_t)f * L.blurFrameStride;
-        const int dpitch = L.pitch;
-        const int xl = (tid & 15) * 4;
-        const int yp = tid >> 4;  // 0..15
-        const int gy = y0 + 2 * yp, gx = x0 + xl;
-        if (gy < h && gx < w) {
-            const uint4 p0 = *reinterpret_cast<const uint4*>(&sTmp[yp][xl]);
-            const uint4 p1 = *reinterpret_cast<const uint4*>(&sTmp[yp + 1][xl]);
-            const uint4 p2 = *reinterpret_cast<const uint4*>(&sTmp[yp + 2][xl]);
-            const uint32_t c0[4] = {p0.x, p0.y, p0.z, p0.w}, c1[4] = {p1.x, p1.y, p1.z, p1.w}, c2[4] = {p2.x, p2.y, p2.z, p2.w};
-            uint32_t ev[4], od[4];
+    }  // MODE & 1
+
+    // ================= FAST =================
+    // tested region 6 <= x <= w-6, 6 <= y <= h-6 (Fast_gpu.cu:275,365-368: strict compares
+    // against border 5 and dim-5); scores are needed for the tile + 1-px halo (NMS): score position (sy, sx),
+    // sy 0..33, sx 0..65, is the pixel staged at (sy + 3, sx + 3).
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, provably uniform
+    if (wv >= 2) {
+        // waves 2 and 3 clear the score map and run the Gaussian's vertical pass while waves 0 and 1 run stage A
+        if constexpr ((MODE & 2) != 0)
+            for (int e = tid - 128; e < (kScH + 1) * (kScPitch / 4); e += 128) reinterpret_cast<uint32_t*>(&sScore[0][0])[e] = 0;
+        if constexpr ((MODE & 1) != 0) {
+            // vertical pass of the Gaussian for the whole tile: thread -> 4 columns x output rows 2*yp, 2*yp+1 (tmp rows
+            // 2yp..2yp+5 = pairs yp..yp+2), two row pairs per thread; one rounding (+32768 >> 16) folded into the
+            // accumulator init; the result is byte 2 of each accumulator
+            uint8_t* dst = ws + L.blurOff + (size_t)f * L.blurFrameStride;
+            const int dpitch = L.pitch;
+            const int xl = (tid & 15) * 4;
+#pragma unroll 1
+            for (int yp = (tid - 128) >> 4; yp < kFastTH / 2; yp += 8) {
+                const int gy = y0 + 2 * yp, gx = x0 + xl;
+                if (gy < h && gx < w) {
+                    const uint4 p0 = *reinterpret_cast<const uint4*>(&sTmp[yp][xl]);
+                    const uint4 p1 = *reinterpret_cast<const uint4*>(&sTmp[yp + 1][xl]);
+                    const uint4 p2 = *reinterpret_cast<const uint4*>(&sTmp[yp + 2][xl]);
+                    const uint32_t c0[4] = {p0.x, p0.y, p0.z, p0.w}, c1[4] = {p1.x, p1.y, p1.z, p1.w}, c2[4] = {p2.x, p2.y, p2.z, p2.w};
+                    uint32_t ev[4], od[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const us2 a = __builtin_bit_cast(us2, c0[i]), b = __builtin_bit_cast(us2, c1[i]), c = __builtin_bit_cast(us2, c2[i]);
-                // even row 2yp: tmp rows 2yp..2yp+4 -> taps (22,62 | 88,62 | 22,-)
-                uint32_t acc = __builtin_amdgcn_udot2(a, __builtin_bit_cast(us2, 0x003E0016u), 32768u, false);
-                acc = __builtin_amdgcn_udot2(b, __builtin_bit_cast(us2, 0x003E0058u), acc, false);
-                ev[i] = __builtin_amdgcn_udot2(c, __builtin_bit_cast(us2, 0x00000016u), acc, false);
-                // odd row 2yp+1: tmp rows 2yp+1..2yp+5 -> taps (-,22 | 62,88 | 62,22)
-                acc = __builtin_amdgcn_udot2(a, __builtin_bit_cast(us2, 0x00160000u), 32768u, false);
-                acc = __builtin_amdgcn_udot2(b, __builtin_bit_cast(us2, 0x0058003Eu), acc, false);
-                od[i] = __builtin_amdgcn_udot2(c, __builtin_bit_cast(us2, 0x0016003Eu), acc, false);
-            }
-            // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00
-            const uint32_t outE = __builtin_amdgcn_perm(ev[1], ev[0], 0x0c0c0602u) |
-                                  (__builtin_amdgcn_perm(ev[3], ev[2], 0x0c0c0602u) << 16);
-            const uint32_t outO = __builtin_amdgcn_perm(od[1], od[0], 0x0c0c0602u) |
-                                  (__builtin_amdgcn_perm(od[3], od[2], 0x0c0c0602u) << 16);
-            uint8_t* drow = dst + (size_t)gy * dpitch;
-            const bool odd = gy + 1 < h;
-            if (gx + 3 < w) {
-                *reinterpret_cast<uint32_t*>(drow + gx) = outE;  // dpitch % 64 == 0, gx % 4 == 0
-                if (odd) *reinterpret_cast<uint32_t*>(drow + dpitch + gx) = outO;
-            } else {
-                for (int i = 0; gx + i < w; i++) {
-                    drow[gx + i] = (uint8_t)(outE >> (8 * i));
-                    if (odd) drow[dpitch + gx + i] = (uint8_t)(outO >> (8 * i));
+                    for (int i = 0; i < 4; i++) {
+                        const u16x2 a = __builtin_bit_cast(u16x2, c0[i]), b = __builtin_bit_cast(u16x2, c1[i]), c = __builtin_bit_cast(u16x2, c2[i]);
+                        // even row 2yp: tmp rows 2yp..2yp+4 -> taps (22,62 | 88,62 | 22,-)
+                        uint32_t acc = __builtin_amdgcn_udot2(a, __builtin_bit_cast(u16x2, 0x003E0016u), 32768u, false);
+                        acc = __builtin_amdgcn_udot2(b, __builtin_bit_cast(u16x2, 0x003E0058u), acc, false);
+                        ev[i] = __builtin_amdgcn_udot2(c, __builtin_bit_cast(u16x2, 0x00000016u), acc, false);
+                        // odd row 2yp+1: tmp rows 2yp+1..2yp+5 -> taps (-,22 | 62,88 | 62,22)
+                        acc = __builtin_amdgcn_udot2(a, __builtin_bit_cast(u16x2, 0x00160000u), 32768u, false);
+                        acc = __builtin_amdgcn_udot2(b, __builtin_bit_cast(u16x2, 0x0058003Eu), acc, false);
+                        od[i] = __builtin_amdgcn_udot2(c, __builtin_bit_cast(u16x2, 0x0016003Eu), acc, false);
+                    }
+                    // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00
+                    const uint32_t outE = __builtin_amdgcn_perm(ev[1], ev[0], 0x0c0c0602u) |
+                                          (__builtin_amdgcn_perm(ev[3], ev[2], 0x0c0c0602u) << 16);
+                    const uint32_t outO = __builtin_amdgcn_perm(od[1], od[0], 0x0c0c0602u) |
+                                          (__builtin_amdgcn_perm(od[3], od[2], 0x0c0c0602u) << 16);
+                    uint8_t* drow = dst + (size_t)gy * dpitch;
+                    const bool odd = gy + 1 < h;
+                    if (gx + 3 < w) {
+                        *reinterpret_cast<uint32_t*>(drow + gx) = outE;  // dpitch % 64 == 0, gx % 4 == 0
+                        if (odd) *reinterpret_cast<uint32_t*>(drow + dpitch + gx) = outO;
+                    } else {
+                        for (int i = 0; gx + i < w; i++) {
+                            drow[gx + i] = (uint8_t)(outE >> (8 * i));
+                            if (odd) drow[dpitch + gx + i] = (uint8_t)(outO >> (8 * i));
+                        }
+                    }
                 }
             }
         }
+    } else if constexpr ((MODE & 2) != 0) {
+        // ---- stage A: compass test.  Ring bits 0 (+3,0), 4 (0,+3), 8 (-3,0), 12 (0,-3): nine consecutive ring
+        //      positions always contain two ADJACENT compass points, the compass cycle 0-4-8-12 is bipartite
+        //      ({0,8} vs {4,12}) and every cross pair is adjacent, so a corner needs
+        //      min(max(N,S), max(E,W)) > v + th  or  max(min(N,S), min(E,W)) < v - th.
+        //      Lane = (column group g of 4 staged columns, strip s of 5 score rows); values are 16-bit pairs of
+        //      horizontally adjacent pixels, so every packed instruction tests two positions ----
+        const int t = tid;
+        const int s = min(t / kGroups, kStrips - 1);
+        const int g = t - (t / kGroups) * kGroups;
+        const uint8_t* base = &sImg[kStripRows * s][4 * g];  // staged rows 5s .. 5s+10
+        uint32_t ca[kStripRows + 6], cb[kStripRows + 6];     // centre pairs (cols 0,1) and (cols 2,3) of the 11 rows
+#pragma unroll
+        for (int i = 0; i < kStripRows + 6; i++) {
+            const uint32_t d1 = *reinterpret_cast<const uint32_t*>(base + i * kImgW);
+            ca[i] = __builtin_amdgcn_perm(0u, d1, 0x0c010c00u);
+            cb[i] = __builtin_amdgcn_perm(0u, d1, 0x0c030c02u);
+        }
+        const uint32_t thPk = (uint32_t)minTh * 0x00010001u;
+        uint32_t dneg[kStripRows][2];  // sign bit of a half set <=> that position passes
+#pragma unroll
+        for (int i = 0; i < kStripRows; i++) {
+            const uint8_t* rp = base + (i + 3) * kImgW;
+            const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rp - 4);
+            const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rp);
+            const uint32_t d2 = *reinterpret_cast<const uint32_t*>(rp + 4);
+            const uint32_t ea = __builtin_amdgcn_perm(d2, d1, 0x0c040c03u);  // cols 3,4
+            const uint32_t eb = __builtin_amdgcn_perm(d2, d1, 0x0c060c05u);  // cols 5,6
+            const uint32_t wa = __builtin_amdgcn_perm(d1, d0, 0x0c020c01u);  // cols -3,-2
+            const uint32_t wb = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);  // cols -1,0
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint32_t n = p ? cb[i] : ca[i], so = p ? cb[i + 6] : ca[i + 6], c = p ? cb[i + 3] : ca[i + 3];
+                const uint32_t e = p ? eb : ea, wq = p ? wb : wa;
+                const uint32_t hiPair = pk_min_u(pk_max_u(n, so), pk_max_u(e, wq));
+                const uint32_t loPair = pk_max_u(pk_min_u(n, so), pk_min_u(e, wq));
+                const uint32_t m = pk_max_i(pk_sub(hiPair, c), pk_sub(c, loPair));
+                dneg[i][p] = pk_sub(thPk, m);
+            }
+        }
+        // validity of the lane's 4 columns / 5 rows as lane masks: staged column c is tested iff cLo <= c <= cHi
+        // (score columns 0..65 inside the FAST region kEdge < x < w - kEdge), staged row r iff rLo <= r <= rHi
+        const int cLo = max(3, kEdge + 1 - (x0 - 4)), cHi = min(kScW + 2, w - kEdge - 1 - (x0 - 4));
+        const int rLo = max(3, kEdge + 1 - (y0 - 4)), rHi = min(kScH + 2, h - kEdge - 1 - (y0 - 4));
+        const uint32_t cSpan = (uint32_t)max(cHi - cLo, -1), rSpan = (uint32_t)max(rHi - rLo, -1);  // -1: nothing valid
+        const uint32_t cRel = t < kTasks ? (uint32_t)(4 * g - cLo) : 0x40000000u;
+        const uint32_t rRel = (uint32_t)(kStripRows * s + 3 - rLo);
+        unsigned long long colOK[4], rowOK[kStripRows];
+#pragma unroll
+        for (int j = 0; j < 4; j++) colOK[j] = cSpan == 0xffffffffu ? 0ull : mask_le_u32(cRel + j, cSpan);
+#pragma unroll
+        for (int i = 0; i < kStripRows; i++) rowOK[i] = rSpan == 0xffffffffu ? 0ull : mask_le_u32(rRel + i, rSpan);
+        // compaction: wave 0 writes slots 0, 1, ... ; wave 1 writes slots kQCap-1, kQCap-2, ... -- the byte address of
+        // the wave's next slot lives in a scalar, +-2 per entry (no reservation, no atomics)
+        const int e0 = (kStripRows * s + 3) * kImgW + 4 * g;  // staged byte offset of the lane's first position
+        const int qStep = wv ? -2 : 2;
+        const int qStepV = (tid & 64) ? -2 : 2;  // the same in a vector register (one SGPR operand per VOP3 on gfx9)
+        const int qBase = (int)(reinterpret_cast<uintptr_t>(&sQA[0]) & 0xffffu);  // LDS byte address of the queue
+        int qNext = qBase + (wv ? 2 * (kQCap - 1) : 0);
+        uint32_t nq = 0;
+#pragma unroll
+        for (int i = 0; i < kStripRows; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t entry = (uint32_t)(e0 + i * kImgW + j);
+                const int cnt = (j & 1) ? queue_slot<true>(dneg[i][j >> 1], colOK[j], rowOK[i], entry, qStepV, qNext)
+                                        : queue_slot<false>(dneg[i][j >> 1], colOK[j], rowOK[i], entry, qStepV, qNext);
+                nq += (uint32_t)cnt;
+                qNext += cnt * qStep;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the queue stores above are not counted by the compiler
+        if (lane == 0) sQ[wv] = nq;
     }
-
-    }  // MODE & 1
 
     if constexpr ((MODE & 2) != 0) {
-    // ================= FAST =================
-    // tested region 6 <= x <= w-6, 6 <= y <= h-6 (Fast_gpu.cu:275,365-368: strict compares
-    // against border 5 and dim-5); scores are needed for the tile + 1-px halo (NMS)
-    // stage A: compass test on every position, survivors -> queue A; scores default to 0.
-    // Column strips: lane = score column, the 4 waves split the 34 score rows (9,9,8,8); the 68 positions of
-    // score columns 64,65 (right halo) fill the ninth slot of waves 2 and 3, so every wave does nine
-    // evaluations.  The pass flags stay wave-wide lane masks (the compare result itself): one LDS atomic per
-    // wave reserves its queue slots and v_mbcnt ranks the lanes -- no per-lane bit masks, no block scan.
-    for (int e = tid; e < kScH * (kScPitch / 4); e += 256) reinterpret_cast<uint32_t*>(&sScore[0][0])[e] = 0;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, provably uniform
-    {
-        const int syBeg = wv * 9 - (wv > 2 ? wv - 2 : 0);  // 0, 9, 18, 26
-        const int px = x0 - 1 + lane;
-        const bool xok = px > kEdge && px < w - kEdge;
-        bool fl[9];
-        int ent[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            int sy = syBeg + k, sx = lane;
-            bool ok = xok;
-            if (k == 8 && wv >= 2) {  // wave-uniform: halo positions 0..63 (wave 2) and 64..67 (wave 3)
-                const int hp = lane + 64 * (wv - 2);
-                sy = min(hp >> 1, kScH - 1);
-                sx = kFastTW + (hp & 1);
-                const int qx = x0 - 1 + sx;
-                ok = hp < 2 * kScH && qx > kEdge && qx < w - kEdge;
-            }
-            const int py = y0 - 1 + sy;
-            ok = ok && py > kEdge && py < h - kEdge;
-            fl[k] = compass_pass_ptr(&sImg[sy + 3][sx + 3], minTh) && ok;
-            ent[k] = (sy << 7) | sx;
-        }
-        uint32_t tot = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) tot += (uint32_t)__popcll(__ballot(fl[k]));
-        uint32_t base = 0;
-        if (tot) {  // wave-uniform
-            if (lane == 0) base = atomicAdd(&sQ[0], tot);
-            base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const unsigned long long m = __ballot(fl[k]);
-                if (fl[k])
-                    sQA[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base))] = (uint16_t)ent[k];
-                base += (uint32_t)__popcll(m);
-            }
-        }
-    }
     __syncthreads();
-    // stage B: corner margin on queue A (dense); corners -> score map + queue B
+    // ---- stage B: segment test + corner score of two queued pixels per lane; corners -> score map + corner queue ----
     if constexpr ((MODE & 4) == 0) {
-        const int nA = (int)sQ[0];
-        const int itB = (nA + 255) / 256;
+        const int n0 = __builtin_amdgcn_readfirstlane((int)sQ[0]), n1 = __builtin_amdgcn_readfirstlane((int)sQ[1]);
+        const int np0 = (n0 + 1) >> 1, npT = np0 + ((n1 + 1) >> 1);
+        const uint32_t* qd = reinterpret_cast<const uint32_t*>(sQA);
+        const uint8_t* img = &sImg[0][0];
 #pragma unroll 1
-        for (int it = 0; it < itB; it++) {
-            const int i = tid + it * 256;
-            bool corner = false;
-            uint16_t e = 0;
-            if (i < nA) {
-                e = sQA[i];
-                const int sy = e >> 7;
-                const int sx = e & 127;
-                const int margin = corner_margin(sImg, sy + 3, sx + 3);
-                corner = margin > minTh;
-                if (corner) sScore[sy][sx] = (uint8_t)(margin - 1);
+        for (int q0 = wv * 64; q0 < npT; q0 += 256) {   // wave-uniform trip count
+            const int q = q0 + lane;
+            const bool act = q < npT;
+            const bool seg1 = q >= np0;
+            // wave 0's pair q = slots 2q, 2q+1; wave 1's pair q' = slots kQCap-1-2q', kQCap-2-2q' = dword kQCap/2-1-q'
+            uint32_t e01 = act ? qd[seg1 ? kQCap / 2 - 1 - (q - np0) : q] : (uint32_t)kScoreOfs * 0x00010001u;
+            if (seg1) e01 = __builtin_amdgcn_alignbit(e01, e01, 16);  // first entry of the pair in the low half
+            const bool two = seg1 ? 2 * (q - np0) + 1 < n1 : 2 * q + 1 < n0;  // false for inactive lanes too
+            const uint32_t eA = e01 & 0xffffu;
+            const uint32_t eB = two ? e01 >> 16 : eA;
+            // a lane (half) without a pixel never passes: its threshold is the largest 16-bit value
+            const int thA = act ? minTh : 0x7fff, thB = two ? minTh : 0x7fff;
+            const uint8_t* pa = img + eA;  // centre of pixel A in the staged tile
+            const uint8_t* pb = img + eB;
+            // ring position k <-> (dy, dx): 0:(3,0) 1:(3,1) 2:(2,2) 3:(1,3) 4:(0,3) 5:(-1,3) 6:(-2,2) 7:(-3,1) 8:(-3,0)
+            // 9:(-3,-1) 10:(-2,-2) 11:(-1,-3) 12:(0,-3) 13:(1,-3) 14:(2,-2) 15:(3,-1)
+            constexpr int ro[16] = {3 * kImgW,      3 * kImgW + 1,  2 * kImgW + 2,  kImgW + 3,  3,  -kImgW + 3, -2 * kImgW + 2, -3 * kImgW + 1,
+                                    -3 * kImgW,     -3 * kImgW - 1, -2 * kImgW - 2, -kImgW - 3, -3, kImgW - 3,  2 * kImgW - 2,  3 * kImgW - 1};
+            uint32_t p[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) p[k] = (uint32_t)pa[ro[k]] | ((uint32_t)pb[ro[k]] << 16);
+            const uint32_t v = (uint32_t)pa[0] | ((uint32_t)pb[0] << 16);
+            const uint32_t hi = pk_sub(arc_extreme<false>(p), v);
+            const uint32_t lo = pk_sub(v, arc_extreme<true>(p));
+            const uint32_t margin = pk_max_i(hi, lo);
+            const int mA = (short)(margin & 0xffffu), mB = (int)margin >> 16;
+            const bool cornerA = mA > thA;
+            const bool cornerB = mB > thB;
+            if (cornerA) sScore[0][eA - kScoreOfs] = (uint8_t)(mA - 1);
+            if (cornerB) sScore[0][eB - kScoreOfs] = (uint8_t)(mB - 1);
+            // corner queue: one reservation per wave for both halves
+            const unsigned long long ma = __builtin_amdgcn_ballot_w64(cornerA), mb = __builtin_amdgcn_ballot_w64(cornerB);
+            const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
+            if (na + nb) {  // wave-uniform
+                uint32_t qb = 0;
+                if (lane == 0) qb = lds_add_rtn(&sQ[2], na + nb);
+                qb = __builtin_amdgcn_readfirstlane(qb);
+                if (cornerA) sQB[__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u)) + qb] = (uint16_t)eA;
+                if (cornerB)
+                    sQB[__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u)) + (qb + na)] = (uint16_t)eB;
             }
-            queue_push(corner, e, sQB, &sQ[1], lane);
         }
     }
     __syncthreads();
-    const int nB = (MODE & 8) ? 0 : (int)sQ[1];
+    const int nB = (MODE & 8) ? 0 : (int)sQ[2];
 
     // ---- NMS (strictly greater than all 8 neighbours, Fast_gpu.cu:300-310) + tile compaction,
     //      again over the dense corner queue; halo corners only serve as neighbours ----
     {
-        const int itN = (nB + 255) / 256;
 #pragma unroll 1
-        for (int it = 0; it < itN; it++) {
-            const int i = tid + it * 256;
+        for (int i = tid; i < ((nB + 63) & ~63); i += 256) {
             bool pre = false, keep = false, hi = false;
             int ox = 0, oy = 0, s = 0;
             if (i < nB) {
-                const uint32_t q = sQB[i];
-                const int sy = (int)((q >> 7) & 63u);
-                const int sx = (int)(q & 127u);
-                ox = sx - 1;
-                oy = sy - 1;
+                const uint32_t e = sQB[i];
+                const uint32_t r = (e * 3641u) >> 18;  // e / 72 for e < 2952
+                ox = (int)(e - r * kImgW) - 4;
+                oy = (int)r - 4;
                 pre = ox >= 0 && ox < kFastTW && oy >= 0 && oy < kFastTH;  // interior: counted once
                 if (pre) {
-                    s = sScore[sy][sx];
+                    const uint8_t* sp = &sScore[0][0] + (e - kScoreOfs);
+                    s = sp[0];
                     hi = s >= iniTh;
                     atomicAdd(&sRow[oy], hi ? 0x10001u : 1u);  // only read by the exact-cap path of the quadtree kernel
                     // strictly greater than all eight == greater than their maximum (three v_max3 + one v_max)
-                    const int n0 = max(max((int)sScore[sy - 1][sx - 1], (int)sScore[sy - 1][sx]), (int)sScore[sy - 1][sx + 1]);
-                    const int n1 = max(max((int)sScore[sy][sx - 1], (int)sScore[sy][sx + 1]), (int)sScore[sy + 1][sx - 1]);
-                    const int n2 = max((int)sScore[sy + 1][sx], (int)sScore[sy + 1][sx + 1]);
+                    const int n0 = max(max((int)sp[-kScPitch - 1], (int)sp[-kScPitch]), (int)sp[-kScPitch + 1]);
+                    const int n1 = max(max((int)sp[-1], (int)sp[1]), (int)sp[kScPitch - 1]);
+                    const int n2 = max((int)sp[kScPitch], (int)sp[kScPitch + 1]);
                     keep = s > max(max(n0, n1), n2);
                 }
             }
-            const unsigned long long mPre = __ballot(pre);
+            const unsigned long long mPre = __builtin_amdgcn_ballot_w64(pre);
             if (mPre == 0) continue;  // wave-uniform
-            const unsigned long long mPreHi = __ballot(pre && hi);
-            const unsigned long long mKeep = __ballot(keep);
-            const unsigned long long mKeepHi = __ballot(keep && hi);
+            const unsigned long long mPreHi = __builtin_amdgcn_ballot_w64(pre && hi);
+            const unsigned long long mKeep = __builtin_amdgcn_ballot_w64(keep);
+            const unsigned long long mKeepHi = __builtin_amdgcn_ballot_w64(keep && hi);
             uint32_t wbase = 0;
             if (lane == 0) {
                 atomicAdd(&sCnt[2], (uint32_t)__popcll(mPre));
@@ -473,19 +605,24 @@ void fast_tiles_for(int w, int h, int* tx, int* ty)
     *ty = (h + kFastTH - 1) / kFastTH;
 }
 
-void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
-                      size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws, uint32_t* cand,
-                      uint32_t* counters, uint32_t* tileRows)
+uint32_t fast_tile_info(int level, int tileX, int tileY) { return ((uint32_t)level << 24) | ((uint32_t)tileY << 12) | (uint32_t)tileX; }
+
+void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint32_t* dTileInfo,
+                      const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws,
+                      uint32_t* cand, uint32_t* counters, uint32_t* tileRows)
 {
     dim3 block(256);
     dim3 grid(frames, totalTiles);
+#define ORBFE_LAUNCH_FB(M)                                                                                          \
+    hipLaunchKernelGGL(fast_blur_kernel<M>, grid, block, 0, s, dP, dTileInfo, gray0, gray0FrameStride, gray0Pitch, \
+                       gray0Aligned4, ws, cand, counters, tileRows)
+#ifdef ORBFE_ABLATION
+    // timing-only build (liborbfe_ablation.so, `make ablation`): ORBFE_FAST_MODE selects a truncated kernel whose
+    // RESULTS ARE WRONG unless it is 3.  The shipped library does not contain these variants and reads no variable.
     static const int mode = [] {
-        const char* e = getenv("ORBFE_FAST_MODE");  // timing experiments only; results are wrong unless 3
+        const char* e = getenv("ORBFE_FAST_MODE");
         return e ? atoi(e) & 15 : 3;
     }();
-#define ORBFE_LAUNCH_FB(M)                                                                               \
-    hipLaunchKernelGGL(fast_blur_kernel<M>, grid, block, 0, s, dP, gray0, gray0FrameStride, gray0Pitch, \
-                       gray0Aligned4, ws, cand, counters, tileRows)
     switch (mode) {
     case 0: ORBFE_LAUNCH_FB(0); break;
     case 1: ORBFE_LAUNCH_FB(1); break;
@@ -494,6 +631,9 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
     case 10: ORBFE_LAUNCH_FB(10); break;  // FAST stages A + B only
     default: ORBFE_LAUNCH_FB(3); break;
     }
+#else
+    ORBFE_LAUNCH_FB(3);
+#endif
 #undef ORBFE_LAUNCH_FB
 }
 

@@ -11,9 +11,10 @@ void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFram
 
 // kernels_fast.hip (FAST + NMS + compaction fused with the Gaussian blur of the same tile)
 void fast_tiles_for(int w, int h, int* tx, int* ty);
-void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint8_t* gray0,
-                      size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws, uint32_t* cand,
-                      uint32_t* counters, uint32_t* tileRows);
+uint32_t fast_tile_info(int level, int tileX, int tileY);  // entry of the per-tile table (level << 24 | ty << 12 | tx)
+void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint32_t* dTileInfo,
+                      const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws,
+                      uint32_t* cand, uint32_t* counters, uint32_t* tileRows);
 
 // kernels_quadtree.hip
 int quadtree_node_capacity(int maxNodeCap);

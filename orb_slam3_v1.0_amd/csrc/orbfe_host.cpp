@@ -55,6 +55,7 @@ struct orbfe_handle {
     uint32_t* dTileRows = nullptr;  // [frame][FAST tile][32] pre-NMS corner counts per tile row
     uint8_t* dQtScratch = nullptr;  // node tables of the large-N quadtree variant, [level][frame] slabs
     uint32_t* dTabs = nullptr;      // resize tables
+    uint32_t* dTileInfo = nullptr;  // FAST tile -> (level, tile column, tile row)
     float* dSf = nullptr;           // mvScaleFactor on the device (batched matcher)
 
     // staging for the host-pointer API
@@ -139,7 +140,7 @@ void destroy_impl(orbfe_handle* h)
     for (auto& g : h->graphs)
         if (g.second) (void)hipGraphExecDestroy(g.second);
     void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTileRows, h->dQtScratch, h->dTabs,
-                     h->dSf, h->dIn, h->dOutBlock};
+                     h->dTileInfo, h->dSf, h->dIn, h->dOutBlock};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     void* hptrs[] = {h->hIn, h->hOutBlock};
@@ -317,6 +318,14 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     if (quadtree_scratch_bytes_per_block(h->maxNodeCap))
         CREATE_CHK(hipMalloc(&h->dQtScratch, quadtree_scratch_bytes_per_block(h->maxNodeCap) * B * nL));
     CREATE_CHK(hipMalloc(&h->dTabs, tabs.size() * sizeof(uint32_t)));
+    {
+        std::vector<uint32_t> info((size_t)P.totalTiles);
+        for (int l = 0; l < nL; l++)
+            for (int ty = 0; ty < P.lv[l].tilesY; ty++)
+                for (int tx = 0; tx < P.lv[l].tilesX; tx++) info[P.lv[l].tileBase + ty * P.lv[l].tilesX + tx] = fast_tile_info(l, tx, ty);
+        CREATE_CHK(hipMalloc(&h->dTileInfo, info.size() * sizeof(uint32_t)));
+        CREATE_CHK(hipMemcpy(h->dTileInfo, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     CREATE_CHK(hipMalloc(&h->dSf, kMaxLevels * sizeof(float)));
     CREATE_CHK(hipMemcpy(h->dSf, h->sf, kMaxLevels * sizeof(float), hipMemcpyHostToDevice));
     CREATE_CHK(hipMemcpy(h->dP, &P, sizeof P, hipMemcpyHostToDevice));
@@ -462,7 +471,7 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
                       D.pitch, h->dTabs + D.xtabOff, h->dTabs + D.ytabOff);
     }
     if (ev) HIPCHK(h, hipEventRecord(ev[1], s));
-    launch_fast_blur(s, batch, P.totalTiles, h->dP, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters,
+    launch_fast_blur(s, batch, P.totalTiles, h->dP, h->dTileInfo, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters,
                      h->dTileRows);
     if (ev) HIPCHK(h, hipEventRecord(ev[2], s));
     launch_quadtree(s, batch, nL, h->maxNodeCap, h->dP, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, d_gray, frame_stride,
