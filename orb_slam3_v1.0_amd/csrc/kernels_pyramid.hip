@@ -7,6 +7,8 @@
 //
 // Launch geometry: blockIdx.x = frame (fastest-varying so that frames f and f+8 share an XCD and
 // every tile of one frame hits the same L2), blockIdx.y/z = tile.
+#include <algorithm>
+
 #include "launch.h"
 
 namespace orbfe {
@@ -147,6 +149,175 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
         body([&](int yy, int xx) -> uint32_t { return s[(size_t)yy * spitch + xx]; });
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// pyramid_kernel -- ALL levels of a frame in one launch: one 512-thread block per frame walks the levels in
+// order (level l from the unblurred level l-1, src/ORBextractor.cc:613-621) with a block barrier between levels,
+// so the dependent chain of L-1 launches (and their tails on the small levels) is gone and a level is read back by
+// the compute unit that has just written it.
+//
+// The arithmetic is the same (S1) but organised for few vector instructions (the table-driven tile kernel above
+// spends ~29 per output pixel, this one ~8):
+//   * a WAVE owns a strip of output rows x 256 output columns, a lane 4 adjacent columns; per step of four output
+//     rows the wave copies the (at most kPyrRows) source rows they touch into a wave-private LDS ring with
+//     COALESCED dword loads -- row tables, row addresses and the vertical weights are scalars.  (Letting every lane
+//     fetch its own 12-byte window from global memory costs ~15 L1 accesses per wave instruction -- neighbouring
+//     windows overlap -- and ran at the L1's access rate, 0.36 ms per 512 frames.)
+//   * horizontal pass per source row: the 12 source bytes a lane's 4 outputs can touch come out of LDS as three
+//     dwords, v_perm_b32 with a per-lane selector puts the two taps of an output into the halves of a dword and ONE
+//     v_dot2_u32_u16 against (2048 - wx | wx << 16) gives a * (2048 - wx) + b * wx (<= 255 * 2048);
+//   * vertical pass: top * 4(2048 - wy) + bot * 4 wy + 2^23 with two 24-bit multiply-adds -- the quotient
+//     (v + 2^21) >> 22 is the TOP BYTE of that word, so v_perm_b32 packs four results without shifts.
+// The host checks per level that every tap pair of a lane lies inside its 12-byte window, that four output rows never
+// span more than kPyrRows source rows, that a 256-column chunk spans at most kPyrSegDw source dwords (level ratios up
+// to ~1.45) and that x1 + 1 / y1 + 1 never need the clamp; other levels take the tile kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPyrWaves = 8;
+constexpr int kPyrRows = 7;     // source rows staged per step of 4 output rows
+constexpr int kPyrSegDw = 96;   // dwords per staged row segment (256 output columns)
+
+struct PyrPlan {
+    int rowsPerStrip[kMaxLevels];  // 0: level not handled by pyramid_kernel
+    int firstLevel, lastLevel;     // levels firstLevel..lastLevel are produced by this launch
+};
+
+// a * w + c with the 24-bit multiplier (a < 2^19, w <= 8192 scalar); hipcc splits the expression into two multiplies
+// and a three-input add
+__device__ __forceinline__ uint32_t mad24_vsv(uint32_t a, uint32_t w, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(w), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ void pyr_hpass(uint32_t d0, uint32_t d1, uint32_t d2, const uint32_t (&sel)[4], const uint32_t (&wp)[4],
+                                          uint32_t (&h)[4])
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    // columns 0..2 take their taps from window bytes 0..7, column 3 from bytes 3..10
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, 3), e1 = __builtin_amdgcn_alignbyte(d2, d1, 3);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t pair = i < 3 ? __builtin_amdgcn_perm(d1, d0, sel[i]) : __builtin_amdgcn_perm(e1, e0, sel[i]);
+        h[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pair), __builtin_bit_cast(us2, wp[i]), 0u, false);
+    }
+}
+
+__global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineDesc* __restrict__ P, PyrPlan plan,
+                                                                 const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
+                                                                 int gray0Pitch, uint8_t* __restrict__ ws,
+                                                                 const uint32_t* __restrict__ tabs)
+{
+    __shared__ uint32_t sRows[kPyrWaves][kPyrRows][kPyrSegDw];  // wave-private: no block barrier inside a level
+
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* const ring = &sRows[wave][0][0];
+
+    for (int l = plan.firstLevel; l <= plan.lastLevel; l++) {
+        const LevelDesc& S = P->lv[l - 1];
+        const LevelDesc& D = P->lv[l];
+        const int sw = S.w, sh = S.h, dw = D.w, dh = D.h, dpitch = D.pitch;
+        const uint8_t* src = l == 1 ? gray0 + (size_t)f * gray0FrameStride : ws + S.imgOff + (size_t)f * S.imgFrameStride;
+        const int spitch = l == 1 ? gray0Pitch : S.pitch;
+        uint8_t* dst = ws + D.imgOff + (size_t)f * D.imgFrameStride;
+        const uint32_t* xtab = tabs + D.xtabOff;
+        const uint32_t* ytab = tabs + D.ytabOff;
+        const int R = plan.rowsPerStrip[l];
+        const int strips = (dh + R - 1) / R, chunks = (dw + 255) / 256;
+        // source level through a buffer descriptor: rows 0..sh-1, the last one up to its 4-byte-rounded end (the aligned
+        // level-0 contract, orbfe.h); a dword past that reads 0 and can only hold bytes no output uses
+        const __amdgpu_buffer_rsrc_t srsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (sh - 1) * spitch + ((sw + 3) & ~3), 0x00020000);
+        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dh * dpitch, 0x00020000);
+
+        for (int task = wave; task < strips * chunks; task += kPyrWaves) {
+            const int strip = task / chunks, chunk = task - strip * chunks;
+            const int x0 = chunk * 256 + lane * 4;
+            const bool colOk = x0 < dw;
+            // per-lane column constants (lanes past the level width copy the last group: their results are not stored)
+            const int xg = min(x0, (dw - 1) & ~3);
+            const uint4 xt4 = *reinterpret_cast<const uint4*>(xtab + xg);  // table padded to a multiple of 4
+            const uint32_t xt[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
+            const uint32_t start = (xt[0] & 0xffffu) & ~3u;
+            const uint32_t segBase = (xtab[chunk * 256] & 0xffffu) & ~3u;  // scalar: first source byte of the chunk
+            const uint32_t winOff = start - segBase;                        // byte offset of the lane's window in a staged row
+            uint32_t sel[4], wp[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t o = (xt[i] & 0xffffu) - start - (i == 3 ? 3u : 0u);
+                sel[i] = 0x0c000c00u | o | ((o + 1u) << 16);
+                const uint32_t wx = xt[i] >> 16;
+                wp[i] = (2048u - wx) | (wx << 16);
+            }
+            const int nvalid = min(4, dw - x0);
+            const uint32_t ldA = segBase + 4u * (uint32_t)lane, ldB = ldA + 256u;  // the lane's two dwords of a staged row
+            const bool hasB = lane < kPyrSegDw - 64;
+
+            const int ys = strip * R, ye = min(ys + R, dh);
+            uint32_t kRound = 1u << 23;
+            asm("" : "+v"(kRound));  // in a vector register: v_mad_u32_u24 takes one scalar operand (the weight)
+            // software pipeline: the global loads (and row-table entries) of step n + 1 are requested before step n is
+            // computed, so a wave always has kPyrRows x 2 dwords in flight behind its arithmetic
+            uint32_t ytN[4];
+            uint32_t ga[kPyrRows], gb[kPyrRows];
+            auto request = [&](int yb) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) ytN[k] = ytab[min(yb + k, ye - 1)];
+                const int rN = (int)(ytN[0] & 0xffffu);
+#pragma unroll
+                for (int j = 0; j < kPyrRows; j++) {
+                    const uint32_t ro = (uint32_t)(min(rN + j, sh - 1) * spitch);
+                    ga[j] = __builtin_amdgcn_raw_buffer_load_b32(srsrc, ldA, ro, 0);
+                    gb[j] = hasB ? __builtin_amdgcn_raw_buffer_load_b32(srsrc, ldB, ro, 0) : 0u;
+                }
+            };
+            request(ys);
+#pragma unroll 1
+            for (int yb = ys; yb < ye; yb += 4) {
+                uint32_t yt[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) yt[k] = ytN[k];
+                const int rA = (int)(yt[0] & 0xffffu);  // first staged source row
+#pragma unroll
+                for (int j = 0; j < kPyrRows; j++) {
+                    ring[j * kPyrSegDw + lane] = ga[j];
+                    if (hasB) ring[j * kPyrSegDw + 64 + lane] = gb[j];
+                }
+                if (yb + 4 < ye) request(yb + 4);  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int jt = (int)(yt[k] & 0xffffu) - rA;  // staged row of the top taps (scalar), bottom = jt + 1
+                    const uint32_t* wt = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ring + jt * kPyrSegDw) + winOff);
+                    const uint32_t* wb = wt + kPyrSegDw;
+                    uint32_t hT[4], hB[4];
+                    pyr_hpass(wt[0], wt[1], wt[2], sel, wp, hT);
+                    pyr_hpass(wb[0], wb[1], wb[2], sel, wp, hB);
+                    const uint32_t wy4 = (yt[k] >> 16) * 4u, wyc4 = 8192u - wy4;
+                    uint32_t v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = mad24_vsv(hB[i], wy4, mad24_vsv(hT[i], wyc4, kRound));
+                    // result byte = bits 31..24 of each v
+                    const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u);
+                    const uint32_t hi = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0703u);
+                    const uint32_t outw = lo | (hi << 16);
+                    const int y = yb + k;
+                    if (y < ye && colOk) {
+                        if (nvalid == 4) {
+                            __builtin_amdgcn_raw_buffer_store_b32(outw, drsrc, (uint32_t)x0, (uint32_t)(y * dpitch), 0);  // 4-aligned
+                        } else {
+                            for (int i = 0; i < nvalid; i++)
+                                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(outw >> (8 * i)), drsrc, (uint32_t)(x0 + i), (uint32_t)(y * dpitch), 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // level l complete (stores drained by the barrier's release) before level l+1 reads it
+    }
+}
+
 void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFrameStride, int sw, int sh,
                    int spitch, int srcAligned4, uint8_t* dst, size_t dstFrameStride, int dw, int dh, int dpitch,
                    const uint32_t* xtab, const uint32_t* ytab)
@@ -161,6 +332,55 @@ void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFram
     else
         hipLaunchKernelGGL(resize_kernel<kRsMaxRows / 4>, grid, block, 0, s, src, srcFrameStride, sw, sh, spitch, srcAligned4,
                            dst, dstFrameStride, dw, dh, dpitch, xtab, ytab);
+}
+
+
+// Which levels the one-launch kernel can produce: every tap pair of a 4-column group inside the group's 12-byte
+// window in the places pyr_hpass expects, and no clamped far tap (true for level ratios between 1 and ~1.45).
+bool pyramid_level_fits(const uint32_t* xtab, const uint32_t* ytab, int sw, int sh, int dw, int dh)
+{
+    for (int y = 0; y < dh; y++) {
+        if ((int)(ytab[y] & 0xffffu) + 1 > sh - 1) return false;
+        // four output rows starting anywhere (strips start at arbitrary rows) must fit the staged ring
+        const int yl = std::min(y + 3, dh - 1);
+        if ((int)(ytab[yl] & 0xffffu) + 1 - (int)(ytab[y] & 0xffffu) + 1 > kPyrRows) return false;
+    }
+    for (int c0 = 0; c0 < dw; c0 += 256) {
+        // last window of the chunk ends within the staged segment
+        const uint32_t segBase = (xtab[c0] & 0xffffu) & ~3u;
+        const int xl = (std::min(c0 + 256, dw) - 1) & ~3;
+        const uint32_t startL = (xtab[xl] & 0xffffu) & ~3u;
+        if (startL + 12 - segBase > 4u * kPyrSegDw) return false;
+    }
+    for (int x0 = 0; x0 < dw; x0 += 4) {
+        const uint32_t start = (xtab[x0] & 0xffffu) & ~3u;
+        for (int i = 0; i < 4 && x0 + i < dw; i++) {
+            const uint32_t x1 = xtab[x0 + i] & 0xffffu;
+            if ((int)x1 + 1 > sw - 1 || x1 < start) return false;
+            const uint32_t o = x1 - start;
+            if (i < 3 ? o + 1 > 7 : (o < 3 || o - 3 + 1 > 7)) return false;
+        }
+    }
+    return true;
+}
+
+int pyramid_rows_per_strip(int dw, int dh)
+{
+    // about three strips x chunks per wave, strips of at least 8 rows (each strip re-reads one source row)
+    const int chunks = (dw + 255) / 256;
+    const int wantStrips = std::max(1, (3 * kPyrWaves + chunks - 1) / chunks);
+    return std::max(8, (dh + wantStrips - 1) / wantStrips);
+}
+
+void launch_pyramid(hipStream_t s, int frames, const PipelineDesc* dP, const int* rowsPerStrip, int firstLevel, int lastLevel,
+                    const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs)
+{
+    PyrPlan plan{};
+    for (int l = 0; l < kMaxLevels; l++) plan.rowsPerStrip[l] = rowsPerStrip[l];
+    plan.firstLevel = firstLevel;
+    plan.lastLevel = lastLevel;
+    hipLaunchKernelGGL(pyramid_kernel, dim3(frames), dim3(kPyrWaves * 64), 0, s, dP, plan, gray0, gray0FrameStride, gray0Pitch, ws,
+                       tabs);
 }
 
 }  // namespace orbfe

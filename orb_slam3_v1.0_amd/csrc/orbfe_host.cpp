@@ -56,6 +56,7 @@ struct orbfe_handle {
     uint8_t* dQtScratch = nullptr;  // node tables of the large-N quadtree variant, [level][frame] slabs
     uint32_t* dTabs = nullptr;      // resize tables
     uint32_t* dTileInfo = nullptr;  // FAST tile -> (level, tile column, tile row)
+    int pyrRows[kMaxLevels]{};      // rows per wave strip of the one-launch pyramid kernel; 0: level takes the tile kernel
     float* dSf = nullptr;           // mvScaleFactor on the device (batched matcher)
 
     // staging for the host-pointer API
@@ -297,6 +298,11 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
         fill_resize_table(tabs, P.lv[l].ytabOff, P.lv[l - 1].h, P.lv[l].h);
     }
 
+    for (int l = 1; l < nL; l++)
+        if (pyramid_level_fits(tabs.data() + P.lv[l].xtabOff, tabs.data() + P.lv[l].ytabOff, P.lv[l - 1].w, P.lv[l - 1].h, P.lv[l].w,
+                               P.lv[l].h))
+            h->pyrRows[l] = pyramid_rows_per_strip(P.lv[l].w, P.lv[l].h);
+
 #define CREATE_CHK(call)                                                  \
     do {                                                                  \
         hipError_t e_ = (call);                                           \
@@ -309,7 +315,7 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
 
     CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_CHK(hipMalloc(&h->dP, sizeof(PipelineDesc)));
-    CREATE_CHK(hipMalloc(&h->ws, h->wsBytes));
+    CREATE_CHK(hipMalloc(&h->ws, h->wsBytes + 256));  // + slack: the pyramid kernel's 12-byte row windows may end past a level's last row
     CREATE_CHK(hipMalloc(&h->dCand, candOff * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dNodeOf, candOff * sizeof(uint16_t)));
     CREATE_CHK(hipMalloc(&h->dCounters, B * nL * kCntWords * sizeof(uint32_t)));
@@ -460,8 +466,17 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
 
     HIPCHK(h, hipMemsetAsync(h->dCounters, 0, (size_t)batch * nL * kCntWords * sizeof(uint32_t), s));
     if (ev) HIPCHK(h, hipEventRecord(ev[0], s));
-    // ComputePyramid (:607-623): level l from the UNBLURRED level l-1
-    for (int l = 1; l < nL; l++) {
+    // ComputePyramid (:607-623): level l from the UNBLURRED level l-1.  Runs of levels the one-launch kernel can
+    // produce go out as ONE launch (all of them for the usual level ratios); the rest take the tile kernel.
+    for (int l = 1; l < nL;) {
+        const bool fits = h->pyrRows[l] > 0 && (l > 1 || aligned4);
+        if (fits) {
+            int last = l;
+            while (last + 1 < nL && h->pyrRows[last + 1] > 0) last++;
+            launch_pyramid(s, batch, h->dP, h->pyrRows, l, last, d_gray, frame_stride, pitch, h->ws, h->dTabs);
+            l = last + 1;
+            continue;
+        }
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
         const uint8_t* src = l == 1 ? d_gray : h->ws + S.imgOff;
@@ -469,6 +484,7 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
         const int spitch = l == 1 ? pitch : S.pitch;
         launch_resize(s, batch, src, sstride, S.w, S.h, spitch, l == 1 ? aligned4 : 1, h->ws + D.imgOff, D.imgFrameStride, D.w, D.h,
                       D.pitch, h->dTabs + D.xtabOff, h->dTabs + D.ytabOff);
+        l++;
     }
     if (ev) HIPCHK(h, hipEventRecord(ev[1], s));
     launch_fast_blur(s, batch, P.totalTiles, h->dP, h->dTileInfo, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters,
