@@ -8,6 +8,7 @@
 // Launch geometry: blockIdx.x = frame (fastest-varying so that frames f and f+8 share an XCD and
 // every tile of one frame hits the same L2), blockIdx.y/z = tile.
 #include <algorithm>
+#include <cstdlib>
 
 #include "launch.h"
 
@@ -151,18 +152,15 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// pyramid_kernel -- ALL levels of a frame in one launch: one 512-thread block per frame walks the levels in
-// order (level l from the unblurred level l-1, src/ORBextractor.cc:613-621) with a block barrier between levels,
-// so the dependent chain of L-1 launches (and their tails on the small levels) is gone and a level is read back by
-// the compute unit that has just written it.
+// pyramid_kernel -- level l from the unblurred level l-1 (src/ORBextractor.cc:613-621), one launch per level, every
+// wave an independent (strip of output rows) x (256 output columns) task.
 //
 // The arithmetic is the same (S1) but organised for few vector instructions (the table-driven tile kernel above
-// spends ~29 per output pixel, this one ~8):
-//   * a WAVE owns a strip of output rows x 256 output columns, a lane 4 adjacent columns; per step of four output
-//     rows the wave copies the (at most kPyrRows) source rows they touch into a wave-private LDS ring with
-//     COALESCED dword loads -- row tables, row addresses and the vertical weights are scalars.  (Letting every lane
-//     fetch its own 12-byte window from global memory costs ~15 L1 accesses per wave instruction -- neighbouring
-//     windows overlap -- and ran at the L1's access rate, 0.36 ms per 512 frames.)
+// spends ~29 per output pixel, this one ~11):
+//   * a lane owns 4 adjacent output columns; per step of four output rows the wave copies the (at most kPyrRows)
+//     source rows they touch into a wave-private LDS ring with COALESCED dword loads -- row tables, row addresses and
+//     the vertical weights are scalars.  (Letting every lane fetch its own 12-byte window from global memory costs
+//     ~15 L1 accesses per wave instruction -- neighbouring windows overlap -- and ran at the L1's access rate.)
 //   * horizontal pass per source row: the 12 source bytes a lane's 4 outputs can touch come out of LDS as three
 //     dwords, v_perm_b32 with a per-lane selector puts the two taps of an output into the halves of a dword and ONE
 //     v_dot2_u32_u16 against (2048 - wx | wx << 16) gives a * (2048 - wx) + b * wx (<= 255 * 2048);
@@ -171,15 +169,15 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
 // The host checks per level that every tap pair of a lane lies inside its 12-byte window, that four output rows never
 // span more than kPyrRows source rows, that a 256-column chunk spans at most kPyrSegDw source dwords (level ratios up
 // to ~1.45) and that x1 + 1 / y1 + 1 never need the clamp; other levels take the tile kernel above.
+// Measured and rejected: ALL levels of a frame in one launch (one 512- or 1024-thread block per frame, block barrier
+// between levels): a block needs 0.2 ms per frame whatever the batch -- 0.32 ms per 512 frames at 45 % of the VALU
+// issue rate, and slower than the per-level launches below 256 frames.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kPyrWaves = 8;
+constexpr int kPyrWaves = 4;    // waves (independent tasks) per block
+
 constexpr int kPyrRows = 7;     // source rows staged per step of 4 output rows
 constexpr int kPyrSegDw = 96;   // dwords per staged row segment (256 output columns)
 
-struct PyrPlan {
-    int rowsPerStrip[kMaxLevels];  // 0: level not handled by pyramid_kernel
-    int firstLevel, lastLevel;     // levels firstLevel..lastLevel are produced by this launch
-};
 
 // a * w + c with the 24-bit multiplier (a < 2^19, w <= 8192 scalar); hipcc splits the expression into two multiplies
 // and a three-input add
@@ -203,19 +201,19 @@ __device__ __forceinline__ void pyr_hpass(uint32_t d0, uint32_t d1, uint32_t d2,
     }
 }
 
-__global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineDesc* __restrict__ P, PyrPlan plan,
+__global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineDesc* __restrict__ P, int l, int R,
                                                                  const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
                                                                  int gray0Pitch, uint8_t* __restrict__ ws,
                                                                  const uint32_t* __restrict__ tabs)
 {
-    __shared__ uint32_t sRows[kPyrWaves][kPyrRows][kPyrSegDw];  // wave-private: no block barrier inside a level
+    __shared__ uint32_t sRows[kPyrWaves][kPyrRows][kPyrSegDw];  // wave-private: no block barrier
 
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t* const ring = &sRows[wave][0][0];
 
-    for (int l = plan.firstLevel; l <= plan.lastLevel; l++) {
+    {
         const LevelDesc& S = P->lv[l - 1];
         const LevelDesc& D = P->lv[l];
         const int sw = S.w, sh = S.h, dw = D.w, dh = D.h, dpitch = D.pitch;
@@ -224,7 +222,6 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
         uint8_t* dst = ws + D.imgOff + (size_t)f * D.imgFrameStride;
         const uint32_t* xtab = tabs + D.xtabOff;
         const uint32_t* ytab = tabs + D.ytabOff;
-        const int R = plan.rowsPerStrip[l];
         const int strips = (dh + R - 1) / R, chunks = (dw + 255) / 256;
         // source level through a buffer descriptor: rows 0..sh-1, the last one up to its 4-byte-rounded end (the aligned
         // level-0 contract, orbfe.h); a dword past that reads 0 and can only hold bytes no output uses
@@ -232,7 +229,8 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (sh - 1) * spitch + ((sw + 3) & ~3), 0x00020000);
         const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dh * dpitch, 0x00020000);
 
-        for (int task = wave; task < strips * chunks; task += kPyrWaves) {
+        const int task = (int)blockIdx.y * kPyrWaves + wave;
+        if (task < strips * chunks) {
             const int strip = task / chunks, chunk = task - strip * chunks;
             const int x0 = chunk * 256 + lane * 4;
             const bool colOk = x0 < dw;
@@ -314,7 +312,6 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
                 }
             }
         }
-        __syncthreads();  // level l complete (stores drained by the barrier's release) before level l+1 reads it
     }
 }
 
@@ -364,23 +361,16 @@ bool pyramid_level_fits(const uint32_t* xtab, const uint32_t* ytab, int sw, int 
     return true;
 }
 
-int pyramid_rows_per_strip(int dw, int dh)
+void launch_pyramid_level(hipStream_t s, int frames, const PipelineDesc* dP, int level, int dw, int dh, const uint8_t* gray0,
+                          size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs)
 {
-    // about three strips x chunks per wave, strips of at least 8 rows (each strip re-reads one source row)
-    const int chunks = (dw + 255) / 256;
-    const int wantStrips = std::max(1, (3 * kPyrWaves + chunks - 1) / chunks);
-    return std::max(8, (dh + wantStrips - 1) / wantStrips);
-}
-
-void launch_pyramid(hipStream_t s, int frames, const PipelineDesc* dP, const int* rowsPerStrip, int firstLevel, int lastLevel,
-                    const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs)
-{
-    PyrPlan plan{};
-    for (int l = 0; l < kMaxLevels; l++) plan.rowsPerStrip[l] = rowsPerStrip[l];
-    plan.firstLevel = firstLevel;
-    plan.lastLevel = lastLevel;
-    hipLaunchKernelGGL(pyramid_kernel, dim3(frames), dim3(kPyrWaves * 64), 0, s, dP, plan, gray0, gray0FrameStride, gray0Pitch, ws,
-                       tabs);
+    // output rows per wave task: long strips amortise the per-task column setup when the launch fills the chip anyway,
+    // one 4-row step per task keeps a small batch short (a task is a serial chain of steps)
+    static const int envR = getenv("ORBFE_PYR_ROWS") ? atoi(getenv("ORBFE_PYR_ROWS")) : 0;
+    const int R = envR > 0 ? envR : frames >= 128 ? 8 : 4;
+    const int tasks = ((dh + R - 1) / R) * ((dw + 255) / 256);
+    hipLaunchKernelGGL(pyramid_kernel, dim3(frames, (tasks + kPyrWaves - 1) / kPyrWaves), dim3(kPyrWaves * 64), 0, s, dP, level, R, gray0,
+                       gray0FrameStride, gray0Pitch, ws, tabs);
 }
 
 }  // namespace orbfe

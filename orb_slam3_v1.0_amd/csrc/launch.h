@@ -9,11 +9,10 @@ void launch_resize(hipStream_t s, int frames, const uint8_t* src, size_t srcFram
                    int spitch, int srcAligned4, uint8_t* dst, size_t dstFrameStride, int dw, int dh, int dpitch,
                    const uint32_t* xtab, const uint32_t* ytab);
 
-// one launch for all levels (levels whose tables pass pyramid_level_fits; the others take launch_resize)
+// row-streaming level kernel (levels whose tables pass pyramid_level_fits; the others take launch_resize)
 bool pyramid_level_fits(const uint32_t* xtab, const uint32_t* ytab, int sw, int sh, int dw, int dh);
-int pyramid_rows_per_strip(int dw, int dh);
-void launch_pyramid(hipStream_t s, int frames, const PipelineDesc* dP, const int* rowsPerStrip, int firstLevel, int lastLevel,
-                    const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs);
+void launch_pyramid_level(hipStream_t s, int frames, const PipelineDesc* dP, int level, int dw, int dh, const uint8_t* gray0,
+                          size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs);
 
 // kernels_fast.hip (FAST + NMS + compaction fused with the Gaussian blur of the same tile)
 void fast_tiles_for(int w, int h, int* tx, int* ty);

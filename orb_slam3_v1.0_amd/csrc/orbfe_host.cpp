@@ -56,7 +56,7 @@ struct orbfe_handle {
     uint8_t* dQtScratch = nullptr;  // node tables of the large-N quadtree variant, [level][frame] slabs
     uint32_t* dTabs = nullptr;      // resize tables
     uint32_t* dTileInfo = nullptr;  // FAST tile -> (level, tile column, tile row)
-    int pyrRows[kMaxLevels]{};      // rows per wave strip of the one-launch pyramid kernel; 0: level takes the tile kernel
+    bool pyrFits[kMaxLevels]{};     // level is produced by the row-streaming pyramid kernel (else: the table-driven tile kernel)
     float* dSf = nullptr;           // mvScaleFactor on the device (batched matcher)
 
     // staging for the host-pointer API
@@ -301,7 +301,7 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     for (int l = 1; l < nL; l++)
         if (pyramid_level_fits(tabs.data() + P.lv[l].xtabOff, tabs.data() + P.lv[l].ytabOff, P.lv[l - 1].w, P.lv[l - 1].h, P.lv[l].w,
                                P.lv[l].h))
-            h->pyrRows[l] = pyramid_rows_per_strip(P.lv[l].w, P.lv[l].h);
+            h->pyrFits[l] = true;
 
 #define CREATE_CHK(call)                                                  \
     do {                                                                  \
@@ -466,25 +466,19 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
 
     HIPCHK(h, hipMemsetAsync(h->dCounters, 0, (size_t)batch * nL * kCntWords * sizeof(uint32_t), s));
     if (ev) HIPCHK(h, hipEventRecord(ev[0], s));
-    // ComputePyramid (:607-623): level l from the UNBLURRED level l-1.  Runs of levels the one-launch kernel can
-    // produce go out as ONE launch (all of them for the usual level ratios); the rest take the tile kernel.
-    for (int l = 1; l < nL;) {
-        const bool fits = h->pyrRows[l] > 0 && (l > 1 || aligned4);
-        if (fits) {
-            int last = l;
-            while (last + 1 < nL && h->pyrRows[last + 1] > 0) last++;
-            launch_pyramid(s, batch, h->dP, h->pyrRows, l, last, d_gray, frame_stride, pitch, h->ws, h->dTabs);
-            l = last + 1;
-            continue;
-        }
+    // ComputePyramid (:607-623): level l from the UNBLURRED level l-1
+    for (int l = 1; l < nL; l++) {
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
+        if (h->pyrFits[l] && (l > 1 || aligned4)) {
+            launch_pyramid_level(s, batch, h->dP, l, D.w, D.h, d_gray, frame_stride, pitch, h->ws, h->dTabs);
+            continue;
+        }
         const uint8_t* src = l == 1 ? d_gray : h->ws + S.imgOff;
         const size_t sstride = l == 1 ? frame_stride : S.imgFrameStride;
         const int spitch = l == 1 ? pitch : S.pitch;
         launch_resize(s, batch, src, sstride, S.w, S.h, spitch, l == 1 ? aligned4 : 1, h->ws + D.imgOff, D.imgFrameStride, D.w, D.h,
                       D.pitch, h->dTabs + D.xtabOff, h->dTabs + D.ytabOff);
-        l++;
     }
     if (ev) HIPCHK(h, hipEventRecord(ev[1], s));
     launch_fast_blur(s, batch, P.totalTiles, h->dP, h->dTileInfo, d_gray, frame_stride, pitch, aligned4, h->ws, h->dCand, h->dCounters,
