@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the MI355X ORB front-end (BASELINE.json metric).
 
-A "step" is one pass of the hot path -- ORB extraction of a batch of synthetic 752x480 frames that
-are already resident in HBM, followed by SearchByProjection of 2000 map points per frame against
-the fresh keypoints (SURVEY.md section 8d, config C3 recipe).  One process per GPU; for N > 1 launch with
-torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env): every rank works on its own
-shard of frames (weak scaling, no data-path collective) and the per-step results are gathered with
-one RCCL all_gather (the "trivial descriptor gather" of BASELINE.json config 4).
+A "step" is one pass of the hot path -- ORB extraction of a batch of synthetic frames that are already resident in
+HBM, followed by SearchByProjection of 2000 map points per frame against the fresh keypoints (SURVEY.md section 8d,
+config C3 recipe).  One process per GPU; for N > 1 launch with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE
+from the env).  Two multi-GPU modes (`config.workload` names the one that ran):
+  weak    every rank brings its own --batch frames (default for the 752x480 headline workload);
+  strong  BASELINE config 4: --workload batched_1280x720 is 512 frames IN TOTAL, rank r owns shard_range(512, r, N)
+          (64 per GPU at N = 8) -- `value` is still total frames / time.
+Either way there is no data-path collective; the per-step results are gathered with one RCCL all_gather (the "trivial
+descriptor gather" of BASELINE.json config 4).
 
 Prints ONE JSON line on rank 0 (driver contract), including
-  roofline     -- dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s
-  cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) timed on host cores.
+  roofline      dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s, plus the instruction
+                side (`issue`) and the PMC traffic of the committed profile of the SAME sources (`profiles_head`)
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) pinned to one host core
+  value_host_io frames/s with host pointers in and out through the pipelined ring (orbfe_stream_*)
+  matcher       map points/s and brute-force-equivalent Hamming pairs/s of the SearchByProjection stage.
 """
 import argparse
+import contextlib
+import glob
 import json
 import os
 import sys
@@ -27,6 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0  # same guide: measured copy peak
+SIMDS, CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, max clock
 
 WORKLOADS = {
     # name: (nFeatures, nFast, scale, levels, iniTh, minTh, W, H)   [SURVEY.md section 8 S0 defaults]
@@ -34,15 +43,17 @@ WORKLOADS = {
     "batched_1280x720": (2000, 100000, 1.2, 8, 20, 7, 1280, 720),
     "tumvi_1024x1024": (1500, 100000, 1.2, 12, 20, 7, 1024, 1024),
 }
+C4_TOTAL_FRAMES = 512    # BASELINE.json configs[3]: 512 frames 1280x720 in total, sharded over the GPUs
 GRID = (64, 48)          # mFrameGridCols x mFrameGridRows (mono_inertial_node.cpp:187-188)
 MATCH_TH, MATCH_NN = 20.0, 0.85  # Tracking.cc:1108-1113 before IMU init
 N_MAP_POINTS = 2000
+SLOT_BYTES = 60          # gathered record: keypoint 24 + descriptor 32 + match index 4
 
 
-def algorithmic_bytes_per_frame(ex, n_kp):
+def algorithmic_bytes_per_frame(level_w, level_h, n_kp):
     """Compulsory HBM traffic per frame with materialised pyramids (minus the P
     bytes saved by reading each level once for both FAST and the Gaussian)."""
-    px = ex.levelW.astype(np.int64) * ex.levelH.astype(np.int64)
+    px = np.asarray(level_w, np.int64) * np.asarray(level_h, np.int64)
     P = int(px.sum())
     per_stage = {
         "pyramid_resize": int((P - px[-1]) + (P - px[0])),  # read every level but the last, write all but level 0
@@ -55,24 +66,30 @@ def algorithmic_bytes_per_frame(ex, n_kp):
     return per_stage, 4 * P - int(px[0]) - int(px[-1]) + 1317 * int(n_kp)
 
 
-STAGE_KERNEL = {"pyramid_resize": "resize_kernel", "fast_nms_blur": "fast_blur_kernel", "quadtree": "quadtree_kernel",
+STAGE_KERNEL = {"pyramid_resize": "pyramid_kernel", "fast_nms_blur": "fast_blur_kernel", "quadtree": "quadtree_kernel",
                 "orient_brief": "orient_brief_kernel"}
 
 
-def pmc_traffic(stage, workload, batch):
-    """HBM bytes per launch of the stage's kernel from the committed PMC passes (profiles/r01_traffic_pmc.json:
-    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 corrections applied by
-    tools/traffic_report.py).  Counters cannot be read from inside the timed process, so this is the number of the
-    last profiled run of the SAME workload / batch; null otherwise."""
+def profile_for(stage, workload, frames_per_launch):
+    """Counter-derived numbers of the stage's kernel from the newest committed profile summary
+    (profiles/*_kernels.json, tools/profile_all.sh) -- but only if that profile was taken on THESE sources (content
+    hash of csrc/) with the same workload and launch size; otherwise None: counters cannot be read from inside the
+    timed process, and a number of other code would be a wrong number."""
+    from orbfe.provenance import source_sha
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
-        meta = d.get("_meta", {})
-        if meta.get("workload") != workload or meta.get("frames_per_launch") != batch:
-            return None
-        tot = [v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if STAGE_KERNEL[stage] in k]
-        return float(tot[0]) if tot else None  # average over the profiled launches of that kernel
+        sha = source_sha()
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernels.json")), reverse=True):
+            d = json.load(open(f))
+            meta = d.get("_meta", {})
+            run = meta.get("bench_plain") or meta.get("trace") or {}
+            if meta.get("source_sha") != sha or run.get("workload") != workload or run.get("frames_per_step") != frames_per_launch:
+                continue
+            for k, v in d.get("kernels", {}).items():
+                if STAGE_KERNEL[stage] in k:
+                    return {"file": os.path.basename(f), "git_head": meta.get("git_head"), **v}
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    return None
 
 
 def make_map_points(kp, n, desc, M, rng, n_levels, mp_dtype):
@@ -106,27 +123,47 @@ def host_cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args_tuple, frames, budget_s, with_match, mp_dtype):
-    """Single-thread CPU oracle on a bounded sample of the same stream (extract [+ match])."""
+def cpu_baseline(args_tuple, frames, budget_s, with_match, mp_dtype, pin_core=None, warmup=5, min_frames=30):
+    """Single-thread CPU oracle on a bounded sample of the same stream (extract [+ match]), SURVEY.md section 8d:
+    pinned to one core, `warmup` untimed frames, then per-frame times of >= `min_frames` frames (budget permitting);
+    the rate is 1 / MEDIAN frame time.  Returns (frames/s, timed frames)."""
     import oracle_py as O
-    ref = O.Extractor(*args_tuple)
-    W, H = args_tuple[6], args_tuple[7]
-    rng = np.random.default_rng(7)
-    ref.extract(frames[0])  # warm
-    t0 = time.perf_counter()
-    n = 0
-    t_gen = 0.0
-    while n < len(frames) and (time.perf_counter() - t0 - t_gen < budget_s or n < 3):
-        kp, desc, _ = ref.extract(frames[n])
-        if with_match and len(kp):
-            tg = time.perf_counter()
-            mps, mpd = make_map_points(kp, len(kp), desc, N_MAP_POINTS, rng, ref.nLevels, mp_dtype)
-            fv = O.make_frame_view(kp, desc, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors)
-            t_gen += time.perf_counter() - tg  # input synthesis is not part of the measured path
-            O.search_by_projection(fv, mps.view(O.MP_DTYPE), mpd, None, MATCH_TH, MATCH_NN)
-        n += 1
-    dt = time.perf_counter() - t0 - t_gen
-    return n / dt, n
+    old_aff = None
+    if pin_core is not None and hasattr(os, "sched_setaffinity"):
+        try:
+            old_aff = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, {pin_core if pin_core in old_aff else min(old_aff)})
+        except OSError:
+            old_aff = None
+    try:
+        ref = O.Extractor(*args_tuple)
+        W, H = args_tuple[6], args_tuple[7]
+        rng = np.random.default_rng(7)
+
+        def one(img):
+            t0 = time.perf_counter()
+            kp, desc, _ = ref.extract(img)
+            dt = time.perf_counter() - t0
+            if with_match and len(kp):
+                # input synthesis is not part of the measured path
+                mps, mpd = make_map_points(kp, len(kp), desc, N_MAP_POINTS, rng, ref.nLevels, mp_dtype)
+                fv = O.make_frame_view(kp, desc, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors)
+                t1 = time.perf_counter()
+                O.search_by_projection(fv, mps.view(O.MP_DTYPE), mpd, None, MATCH_TH, MATCH_NN)
+                dt += time.perf_counter() - t1
+            return dt
+
+        for i in range(min(warmup, len(frames))):
+            one(frames[i])
+        times, t_start = [], time.perf_counter()
+        i = 0
+        while i < max(min_frames, len(frames)) and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
+            times.append(one(frames[(warmup + i) % len(frames)]))
+            i += 1
+        return 1.0 / float(np.median(times)), len(times)
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
 
 
 def cpu_baseline_all_cores(args_tuple, frames, budget_s, with_match, mp_dtype, threads):
@@ -137,11 +174,114 @@ def cpu_baseline_all_cores(args_tuple, frames, budget_s, with_match, mp_dtype, t
     chunks = [frames[i * per:(i + 1) * per] for i in range(threads) if len(frames[i * per:(i + 1) * per])]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(len(chunks)) as ex:
-        res = list(ex.map(lambda c: cpu_baseline(args_tuple, c, budget_s, with_match, mp_dtype), chunks))
+        res = list(ex.map(lambda c: cpu_baseline(args_tuple, c, budget_s, with_match, mp_dtype, None, 1, 3), chunks))
     wall = time.perf_counter() - t0
     n = sum(r[1] for r in res)
     # aggregate rate = sum of the per-thread rates (each excludes its own input synthesis); wall is reported too
     return sum(r[0] for r in res), n, len(chunks), wall
+
+
+class StepRunner:
+    """One bench step on one rank: extract(step i+1) on stream s1 overlapped with match(step i) on stream s2 through
+    double-buffered outputs, then the per-step RCCL gather of the padded results.  The device work goes through two
+    callables so that the N > 1 path (buffer rotation, packing, all_gather_into_tensor, rank-major layout) also runs
+    under gloo on CPU with a stub extractor (tests/test_distributed_cpu.py):
+        extract_fn(buf, frame_set)  fills buf["kp"|"desc"|"n"|"per"]      (enqueued on s1)
+        match_fn(buf, frame_set)    fills buf["match"|"nmatch"]            (enqueued on s2), or None
+    """
+
+    def __init__(self, device, B, cap, n_levels, extract_fn, match_fn, dist=None, world=1, gather=False, overlap=True,
+                 frame_sets=1):
+        self.dev, self.B, self.cap, self.world = device, B, cap, world
+        self.extract_fn, self.match_fn, self.dist, self.gather = extract_fn, match_fn, dist, gather
+        self.frame_sets = frame_sets
+        self.cuda = device.type == "cuda"
+        self.nbuf = 2 if (match_fn is not None and overlap and self.cuda) else 1
+        self.bufs = []
+        for _ in range(self.nbuf):
+            self.bufs.append(dict(kp=torch.zeros((B, cap, 24), dtype=torch.uint8, device=device),
+                                  desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device=device),
+                                  n=torch.zeros(B, dtype=torch.int32, device=device),
+                                  per=torch.zeros((B, n_levels), dtype=torch.int32, device=device),
+                                  match=torch.full((B, cap), -1, dtype=torch.int32, device=device),
+                                  nmatch=torch.zeros(B, dtype=torch.int32, device=device),
+                                  ev_ext=torch.cuda.Event() if self.cuda else None,
+                                  ev_done=torch.cuda.Event() if self.cuda else None))
+        if gather:
+            self.pack = torch.zeros((B, cap, SLOT_BYTES), dtype=torch.uint8, device=device)
+            self.g_out = torch.zeros((world * B, cap, SLOT_BYTES), dtype=torch.uint8, device=device)  # rank-major
+            self.g_n = torch.zeros(world * B, dtype=torch.int32, device=device)
+        self.s1 = self.s2 = None
+        if self.cuda:
+            self.s1 = torch.cuda.current_stream(device)
+            self.s2 = torch.cuda.Stream(device) if self.nbuf == 2 else self.s1
+        self.count = 0
+        self.match_events = []
+
+    def _on(self, stream):
+        return torch.cuda.stream(stream) if self.cuda else contextlib.nullcontext()
+
+    def step(self, timed=False):
+        b = self.bufs[self.count % self.nbuf]
+        fs = self.count % self.frame_sets
+        self.count += 1
+        if self.nbuf == 2:
+            self.s1.wait_event(b["ev_done"])  # this buffer's previous match (two steps ago) must have finished
+        self.extract_fn(b, fs)
+        if self.nbuf == 2:
+            b["ev_ext"].record(self.s1)
+            self.s2.wait_event(b["ev_ext"])
+        if self.match_fn is not None:
+            if timed and self.cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.s2)
+            self.match_fn(b, fs)
+            if timed and self.cuda:
+                e1.record(self.s2)
+                self.match_events.append((e0, e1))
+        if self.gather:
+            with self._on(self.s2):
+                self.pack[:, :, :24] = b["kp"]
+                self.pack[:, :, 24:56] = b["desc"]
+                self.pack[:, :, 56:] = b["match"].view(torch.uint8).reshape(self.B, self.cap, 4)
+                self.dist.all_gather_into_tensor(self.g_out, self.pack)
+                self.dist.all_gather_into_tensor(self.g_n, b["n"])
+        if self.nbuf == 2:
+            b["ev_done"].record(self.s2)
+        return b
+
+    def match_ms(self):
+        return sum(e0.elapsed_time(e1) for e0, e1 in self.match_events) / max(1, len(self.match_events))
+
+
+def host_io_rate(ex, frames, slot_frames, rounds, pinned):
+    """frames/s through the pipelined ring with HOST pointers in and out (orbfe_stream_*): `frames` ([n][H][W] u8 in
+    host memory, pinned or pageable) are submitted slot by slot, the ring is kept full, and every collected slot is
+    copied into caller arrays (keypoints, descriptors, counts) like orbfe_extract_batch does."""
+    src = torch.from_numpy(frames).pin_memory().numpy() if pinned else frames
+    st = ex.stream(slots=3, slot_frames=slot_frames)
+    n_total = len(src)
+    chunks = [(i, min(slot_frames, n_total - i)) for i in range(0, n_total, slot_frames)]
+
+    def run(n_rounds):
+        done = 0
+        todo = [c for _ in range(n_rounds) for c in chunks]
+        pos = 0
+        while pos < len(todo) or st.in_flight():
+            while pos < len(todo):
+                lo, n = todo[pos]
+                if not st.submit(src[lo:lo + n]):
+                    break
+                pos += 1
+            done += st.collect_raw()[0]
+        return done
+
+    run(1)  # warm: pinned pages touched, kernels loaded
+    t0 = time.perf_counter()
+    done = run(rounds)
+    dt = time.perf_counter() - t0
+    st.close()
+    return done / dt
 
 
 def main():
@@ -149,11 +289,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU (128: 131 k, 256: 142 k, 512: 149 k, 1024: 147 k frames/s)")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU in weak-scaling mode")
     ap.add_argument("--workload", default="euroc_752x480", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="auto: strong (512 frames in total, BASELINE config 4) for batched_1280x720, weak otherwise")
+    ap.add_argument("--frame-sets", type=int, default=3,
+                    help="distinct synthetic frame sets the steps rotate through (3 x 512 x 752x480 = 555 MB: more than "
+                         "the 256 MB Infinity Cache, so level 0 is read from HBM)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the all-cores CPU baseline (0/1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the host-pointer ring measurement (value_host_io)")
+    ap.add_argument("--texture-sweep", action="store_true", help="also time a low-texture and a 1/f-noise stream")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL result gather even at N=1 (a 1-rank process group): exercises the N>1 code path on one GPU")
@@ -184,161 +331,206 @@ def main():
 
     import orbfe
     from orbfe import synth
+    from orbfe.shard import shard_range
     if a.lib:
         orbfe.LIB_PATH = os.path.abspath(a.lib)
 
     cfg = WORKLOADS[a.workload]
     W, H = cfg[6], cfg[7]
-    B = a.batch
+    scaling = a.scaling if a.scaling != "auto" else ("strong" if a.workload == "batched_1280x720" else "weak")
+    if scaling == "strong":
+        lo, hi = shard_range(C4_TOTAL_FRAMES, rank, world)
+        B, frame0, frames_total = hi - lo, lo, C4_TOTAL_FRAMES
+        if B < 1:
+            raise SystemExit("more ranks than frames")
+    else:
+        B, frame0, frames_total = a.batch, rank * a.batch, world * a.batch
+    Bpad = (frames_total + world - 1) // world if scaling == "strong" else B  # gather slots per rank
     M = 0 if a.no_match else N_MAP_POINTS
-    ex = orbfe.ORBextractor(*cfg, device=local_rank, max_batch=B)
+    ex = orbfe.ORBextractor(*cfg, device=local_rank, max_batch=max(B, Bpad))
     matcher = orbfe.ORBmatcher(ex)
     cap = ex.cap
+    n_sets = max(1, a.frame_sets)
 
-    # ---- synthetic stream, resident in HBM before the timed region ----
-    frames = np.stack(list(synth.stream(W, H, B, index0=rank)))
-    d_gray = torch.from_numpy(frames).to(dev)
-    # double-buffered outputs: extraction of step i+1 (stream s1) overlaps the matching of step i (stream s2)
-    nbuf = 2 if (M and not a.no_overlap) else 1
-    bufs = []
-    for _ in range(nbuf):
-        bufs.append(dict(kp=torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev),
-                         desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
-                         n=torch.zeros(B, dtype=torch.int32, device=dev),
-                         per=torch.zeros((B, ex.nlevels), dtype=torch.int32, device=dev),
-                         match=torch.full((B, cap), -1, dtype=torch.int32, device=dev),
-                         nmatch=torch.zeros(B, dtype=torch.int32, device=dev),
-                         ev_ext=torch.cuda.Event(), ev_done=torch.cuda.Event()))
+    # ---- synthetic streams, resident in HBM before the timed region; the steps rotate through n_sets of them ----
+    def gen_sets(stream_fn):
+        sets = [np.stack(list(stream_fn(W, H, B, 1000 * s + frame0))) for s in range(n_sets)]
+        return sets, [torch.from_numpy(f).to(dev) for f in sets]
+
+    frames_sets, d_gray = gen_sets(lambda w, h, n, i0: synth.stream(w, h, n, index0=i0))
     gather = (world > 1 or a.force_gather) and not a.no_gather
-    if gather:
-        pack = torch.zeros((B, cap, 60), dtype=torch.uint8, device=dev)  # kp 24 + desc 32 + match 4
-        g_out = torch.zeros((world * B, cap, 60), dtype=torch.uint8, device=dev)  # rank-major concatenation
-        g_n = torch.zeros(world * B, dtype=torch.int32, device=dev)
-    s1 = torch.cuda.current_stream(dev)
-    s2 = torch.cuda.Stream(dev) if nbuf == 2 else s1
+    state = {"gray": d_gray, "mps": None, "mpd": None}
 
-    def extract(b):
-        ex.extract_batch_device(d_gray.data_ptr(), W * H, W, B, b["kp"].data_ptr(), b["desc"].data_ptr(),
-                                b["n"].data_ptr(), b["per"].data_ptr(), s1.cuda_stream)
+    def extract_fn(b, fs):
+        ex.extract_batch_device(state["gray"][fs].data_ptr(), W * H, W, B, b["kp"].data_ptr(), b["desc"].data_ptr(),
+                                b["n"].data_ptr(), b["per"].data_ptr(), runner.s1.cuda_stream)
 
-    # ---- map points (C3 recipe) from one untimed extraction; resident in HBM as well ----
-    extract(bufs[0])
-    torch.cuda.synchronize(dev)
+    def match_fn(b, fs):
+        matcher.SearchByProjection_batch_device(B, b["kp"].data_ptr(), b["desc"].data_ptr(), b["n"].data_ptr(), cap,
+                                                GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), M, state["mps"][fs].data_ptr(),
+                                                state["mpd"][fs].data_ptr(), None, MATCH_TH, MATCH_NN, b["match"].data_ptr(),
+                                                b["nmatch"].data_ptr(), stream=runner.s2.cuda_stream)
+
+    runner = StepRunner(dev, Bpad, cap, ex.nlevels, extract_fn, match_fn if M else None, dist, world, gather,
+                        not a.no_overlap, n_sets)
+
+    def make_points(sets_gray):
+        """map points (C3 recipe) from one untimed extraction per frame set; resident in HBM as well"""
+        mps_d, mpd_d = [], []
+        b0 = runner.bufs[0]
+        state["gray"] = sets_gray
+        for fs in range(n_sets):
+            extract_fn(b0, fs)
+            torch.cuda.synchronize(dev)
+            kp_h = b0["kp"][:B].cpu().numpy().reshape(B, cap * 24).view(orbfe.KP_DTYPE).reshape(B, cap)
+            desc_h = b0["desc"][:B].cpu().numpy()
+            n_h = b0["n"][:B].cpu().numpy()
+            rng = np.random.default_rng(1234 + rank + 77 * fs)
+            mps_all = np.zeros((B, M), orbfe.MP_DTYPE)
+            mpd_all = np.zeros((B, M, 32), np.uint8)
+            for i in range(B):
+                mps_all[i], mpd_all[i] = make_map_points(kp_h[i], int(n_h[i]), desc_h[i], M, rng, ex.nlevels, orbfe.MP_DTYPE)
+            mps_d.append(torch.from_numpy(mps_all.view(np.uint8).reshape(-1)).to(dev))
+            mpd_d.append(torch.from_numpy(mpd_all.reshape(-1)).to(dev))
+        return mps_d, mpd_d
+
     if M:
-        kp_h = bufs[0]["kp"].cpu().numpy().reshape(B, cap * 24).view(orbfe.KP_DTYPE).reshape(B, cap)
-        desc_h = bufs[0]["desc"].cpu().numpy()
-        n_h = bufs[0]["n"].cpu().numpy()
-        rng = np.random.default_rng(1234 + rank)
-        mps_all = np.zeros((B, M), orbfe.MP_DTYPE)
-        mpd_all = np.zeros((B, M, 32), np.uint8)
-        for b in range(B):
-            mps_all[b], mpd_all[b] = make_map_points(kp_h[b], int(n_h[b]), desc_h[b], M, rng, ex.nlevels, orbfe.MP_DTYPE)
-        d_mps = torch.from_numpy(mps_all.view(np.uint8).reshape(-1)).to(dev)
-        d_mpd = torch.from_numpy(mpd_all.reshape(-1)).to(dev)
-    ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    counter = [0]
-
-    def step(i=None):
-        b = bufs[counter[0] % nbuf]
-        counter[0] += 1
-        if nbuf == 2:
-            s1.wait_event(b["ev_done"])  # this buffer's previous match (two steps ago) must have finished
-        extract(b)
-        if nbuf == 2:
-            b["ev_ext"].record(s1)
-            s2.wait_event(b["ev_ext"])
-        if M:
-            if i is not None:
-                ev_m0[i].record(s2)
-            matcher.SearchByProjection_batch_device(B, b["kp"].data_ptr(), b["desc"].data_ptr(), b["n"].data_ptr(), cap,
-                                                    GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), M, d_mps.data_ptr(),
-                                                    d_mpd.data_ptr(), None, MATCH_TH, MATCH_NN, b["match"].data_ptr(),
-                                                    b["nmatch"].data_ptr(), stream=s2.cuda_stream)
-            if i is not None:
-                ev_m1[i].record(s2)
-        if gather:
-            with torch.cuda.stream(s2):
-                pack[:, :, :24] = b["kp"]
-                pack[:, :, 24:56] = b["desc"]
-                pack[:, :, 56:] = b["match"].view(torch.uint8).reshape(B, cap, 4)
-                dist.all_gather_into_tensor(g_out, pack)
-                dist.all_gather_into_tensor(g_n, b["n"])
-        if nbuf == 2:
-            b["ev_done"].record(s2)
+        state["mps"], state["mpd"] = make_points(d_gray)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    ex.set_stage_timing(True)  # HIP events on the launch stream, inside the timed region
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    barrier()
-    dt = time.perf_counter() - t0
-    stage_ms, ncalls = ex.stage_ms()
-    ex.set_stage_timing(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_run(steps, warmup):
+        for _ in range(warmup):
+            runner.step()
+        torch.cuda.synchronize(dev)
+        ex.set_stage_timing(True)  # HIP events on the launch stream, inside the timed region
+        runner.match_events = []
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.step(timed=True)
+        torch.cuda.synchronize(dev)
+        barrier()
+        dt = time.perf_counter() - t0
+        stage_ms, ncalls = ex.stage_ms()
+        ex.set_stage_timing(False)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, stage_ms, ncalls
 
-    n_kp_mean = float(bufs[0]["n"].float().mean().item())
+    dt, stage_ms, ncalls = timed_run(a.steps, a.warmup)
+    ex.device_status()  # device-side guard flags of the last chain (raises if any is set); outside the timed region
+
+    b_last = runner.bufs[0]
+    n_kp_mean = float(b_last["n"][:B].float().mean().item())
+    n_match_mean = float(b_last["nmatch"][:B].float().mean().item()) if M else None
     if rank == 0:
-        per_stage_bytes, b_frame = algorithmic_bytes_per_frame(ex, n_kp_mean)
+        per_stage_bytes, b_frame = algorithmic_bytes_per_frame(ex.levelW, ex.levelH, n_kp_mean)
         stage_avg = {k: v / max(1, ncalls) for k, v in stage_ms.items()}
         if M:
-            stage_avg["match_projection"] = sum(e0.elapsed_time(e1) for e0, e1 in zip(ev_m0, ev_m1)) / a.steps
-        kernel_stages = [s for s in per_stage_bytes]
-        dom = max(kernel_stages, key=lambda s: stage_avg[s])
+            stage_avg["match_projection"] = runner.match_ms()
+        dom = max(per_stage_bytes, key=lambda s: stage_avg[s])
         dom_ms = stage_avg[dom]
         dom_bytes = per_stage_bytes[dom] * B
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         total_ms = stage_avg["total"]
         what = "extract-only" if not M else "extract + SearchByProjection(%d map points/frame, grid %dx%d, th=%g, nnRatio=%g)" % (
             M, GRID[0], GRID[1], MATCH_TH, MATCH_NN)
+        prof = profile_for(dom, a.workload, B)
+        issue = None
+        if prof and prof.get("valu_per_wave") and prof.get("waves_per_launch"):
+            wi = prof["waves_per_launch"] * prof["valu_per_wave"]
+            issue = {"valu_per_wave": prof["valu_per_wave"], "salu_per_wave": prof.get("salu_per_wave"),
+                     "lds_per_wave": prof.get("lds_per_wave"), "waves": prof["waves_per_launch"],
+                     # waves x valu / (1024 SIMDs x clk / 2 x t): the guide's 2-cycle wave64 VALU rate ...
+                     "issue_frac": wi / (SIMDS * CLK_HZ / 2.0 * dom_ms * 1e-3),
+                     # ... and against the rate tools/valu_rate.hip measures for the integer / packed instructions this
+                     # kernel is made of (4 cycles per wave64 instruction per SIMD; profiles/r02_valu_rate.txt)
+                     "issue_frac_at_measured_4_cycles": wi / (SIMDS * CLK_HZ / 4.0 * dom_ms * 1e-3)}
         out = {
-            "metric": "frames/sec ORB extract+match, 752x480 8-level 1000-feat; bit-exact kp/desc",
-            "value": world * B * a.steps / dt,
+            "metric": "frames/sec ORB %s, %dx%d %d-level %d-feat; bit-exact kp/desc" % (
+                "extract+match" if M else "extract", W, H, cfg[3], cfg[0]),
+            "value": frames_total * a.steps / dt,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s synthetic stream, %s, %d frames/step/GPU resident in HBM, nFeatures=%d levels=%d "
-                                   "scale=%.1f FAST %d/%d nFast=%d" % (a.workload, what, B, cfg[0], cfg[3], cfg[2], cfg[4],
-                                                                         cfg[5], cfg[1]),
-                       "frames_per_step": B * world, "mean_keypoints_per_frame": n_kp_mean,
-                       "mean_matches_per_frame": float(bufs[0]["nmatch"].float().mean().item()) if M else None,
+            "config": {"workload": "%s synthetic stream, %s, %s, frames resident in HBM (%d frame sets in rotation), "
+                                   "nFeatures=%d levels=%d scale=%.1f FAST %d/%d nFast=%d" % (
+                                       a.workload, what,
+                                       "%d frames/step/GPU (weak scaling)" % B if scaling == "weak" else
+                                       "%d frames per step IN TOTAL, %d on this rank (strong scaling, BASELINE config 4)" % (frames_total, B),
+                                       n_sets, cfg[0], cfg[3], cfg[2], cfg[4], cfg[5], cfg[1]),
+                       "frames_per_step": frames_total, "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": n_kp_mean,
+                       "mean_matches_per_frame": n_match_mean,
                        "gather": "rccl all_gather of kp+desc+match per step" if gather else "none",
-                       "streams": "extract(step i+1) || match(step i), double-buffered outputs" if nbuf == 2 else "single stream"},
+                       "streams": "extract(step i+1) || match(step i), double-buffered outputs" if runner.nbuf == 2 else "single stream"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
-                         "traffic": pmc_traffic(dom, a.workload, B),
+                         "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
+                         "profiles_head": prof.get("git_head") if prof else None,
+                         "profile_file": prof.get("file") if prof else None,
+                         "issue": issue,
+                         "limiter": "VALU issue: the kernel's integer min/max, packed-16 and byte-permute instructions cost 4 cycles per "
+                                    "wave64 instruction per SIMD (profiles/r02_valu_rate.txt), see roofline.issue",
+                         "input_set_bytes": int(n_sets * B * W * H),
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
                          "extract_pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
                          "stage_ms_per_step": stage_avg},
         }
+        if M:
+            mm = stage_avg["match_projection"]
+            out["matcher"] = {"ms_per_step": mm, "map_points_per_s": B * M / (mm * 1e-3),
+                              # SURVEY.md 8d: brute force is M x N 256-bit Hamming evaluations per frame; the grid-windowed
+                              # search evaluates a small fraction of them, this is the rate a brute-force matcher would need
+                              "pairs_per_s_bruteforce_equivalent": B * M * n_kp_mean / (mm * 1e-3),
+                              "note": "stage time on its own stream while the next step's extraction runs beside it"}
+        if not a.no_host_io and world == 1 and scaling == "weak":
+            slot = min(256, B)
+            try:
+                out["value_host_io"] = host_io_rate(ex, frames_sets[0], slot, 4, True)
+                out["value_host_io_pageable"] = host_io_rate(ex, frames_sets[0], slot, 2, False)
+                out["host_io"] = {"unit": "frames/s", "what": "extract only, host pointers in (pinned / pageable numpy rows) and out, "
+                                  "ring of 3 slots x %d frames, H2D || kernels || D2H on three streams" % slot,
+                                  "pcie_ceiling_frames_per_s": 63e9 / (W * H + 60 * n_kp_mean)}
+            except orbfe.OrbfeError as e:  # report, do not lose the headline line
+                out["host_io"] = {"error": str(e)}
+        if a.texture_sweep and world == 1:
+            sweep = {"default": out["value"]}
+            for name, fn in (("low_texture", lambda w, h, n, i0: synth.stream(w, h, n, index0=i0, density=0.0002)),
+                             ("pink_noise", lambda w, h, n, i0: synth.pink_stream(w, h, n, index0=i0))):
+                _, dg = gen_sets(fn)
+                state["gray"] = dg
+                if M:
+                    state["mps"], state["mpd"] = make_points(dg)
+                nst = max(5, a.steps // 2)
+                dts, st_ms, nc = timed_run(nst, 2)
+                ex.device_status()
+                sweep[name] = {"frames_per_s": frames_total * nst / dts,
+                               "mean_keypoints_per_frame": float(runner.bufs[0]["n"][:B].float().mean().item()),
+                               "fast_ms": st_ms["fast_nms_blur"] / max(1, nc)}
+            out["texture_sweep"] = sweep
         if not a.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            fps, n = cpu_baseline(cfg, frames[:64], a.cpu_seconds, bool(M), orbfe.MP_DTYPE)
+            sample = frames_sets[0][:64]
+            fps, n = cpu_baseline(cfg, sample, a.cpu_seconds, bool(M), orbfe.MP_DTYPE, pin_core=0)
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frames of the same stream through the single-thread C oracle (%s), "
-                                             "host CPU %s, nproc=%d" % (n, what.split("(")[0].strip(), host_cpu_model(), os.cpu_count())}
+                                   "sample": "median frame time of %d frames (after 5 warm-up) of the same stream through the "
+                                             "single-thread C oracle (%s) pinned to one core, host CPU %s, nproc=%d" % (
+                                                 n, what.split("(")[0].strip(), host_cpu_model(), os.cpu_count())}
             if a.cpu_threads > 1:
-                fps_all, n_all, used, wall = cpu_baseline_all_cores(cfg, frames[:min(len(frames), 8 * a.cpu_threads)],
-                                                                    a.cpu_seconds, bool(M), orbfe.MP_DTYPE, a.cpu_threads)
+                fps_all, n_all, used, wall = cpu_baseline_all_cores(cfg, frames_sets[0][:min(B, 8 * a.cpu_threads)],
+                                                                    a.cpu_seconds / 2, bool(M), orbfe.MP_DTYPE, a.cpu_threads)
                 out["cpu_baseline"]["all_cores"] = {"value": fps_all, "unit": "frames/s", "cores": used,
                                                     "sample": "%d frames over %d host threads, %.1f s wall" % (n_all, used, wall)}
         print(json.dumps(out))

@@ -15,6 +15,18 @@
  * Threading: one handle == one HIP stream == one caller at a time for the extract calls (same
  * as the reference).  The matcher calls take their own scratch from the
  * handle and are serialised per handle; use one handle per calling thread.
+ *
+ * Streams: the *_device entry points are asynchronous on the caller's stream but work in scratch the
+ * handle owns (pyramid, candidate lists; the matcher arena).  The library orders consecutive users of
+ * that scratch itself: it records an event behind every enqueue and makes the next enqueue on a
+ * DIFFERENT stream wait for it, so mixing streams (or a *_device call followed by a host-pointer
+ * call) is safe; it does not make two calls run concurrently.
+ *
+ * Input contract of the image entry points: rows `pitch` bytes apart, pitch < 2^24; when the
+ * base address, pitch and frame stride are multiples of 4 the kernels read whole dwords, i.e. up
+ * to the 4-byte-rounded end of every row -- the buffer must extend to
+ * pitch * (height - 1) + ((width + 3) & ~3) bytes per frame (any pitch >= that rounded width, or a
+ * tight width that is a multiple of 4, satisfies it).
  */
 #ifndef ORBFE_H
 #define ORBFE_H
@@ -36,7 +48,8 @@ typedef enum orbfe_status {
     ORBFE_ERR_NO_DEVICE = 3,     /* no gfx950 device / HIP runtime failure at create */
     ORBFE_ERR_HIP = 4,           /* a HIP call failed; see orbfe_last_error() */
     ORBFE_ERR_OUT_OF_MEMORY = 5,
-    ORBFE_ERR_INTERNAL = 6       /* device-side guard tripped (capacity / round limit) */
+    ORBFE_ERR_INTERNAL = 6,      /* device-side guard tripped (capacity / round limit) */
+    ORBFE_ERR_BUSY = 7           /* orbfe_stream_submit: every slot of the ring is in flight -- collect first */
 } orbfe_status;
 
 /* Layout-identical to ORB_SLAM3::KeyPoint (include/KeyPoint.h:7-12): 24 bytes, memcpy-able. */
@@ -113,6 +126,41 @@ int orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, size_t fr
                                int pitch, int batch, orbfe_keypoint *d_kp_out,
                                uint8_t *d_desc_out, int *d_n_out, int *d_per_level_counts,
                                void *stream);
+
+/* Device-side guard flags of the LAST extract call (any entry point, any stream): waits for that
+ * call, ORs the per-(frame, level) status words (candidate-array / node-table overflow, round
+ * limit) into *flags_out (may be NULL) and returns ORBFE_ERR_INTERNAL when any is set.  The
+ * host-pointer entry points check this themselves; callers of orbfe_extract_batch_device do it
+ * here, outside their timed region. */
+int orbfe_get_device_status(orbfe_handle *h, unsigned *flags_out);
+
+/* -------------------------------------------------------------------------------------------
+ * Pipelined host-pointer extraction (the reference's call shape -- a host image per frame,
+ * src/Frame.cc:178-189 -- at stream rate): a ring of `slots` (>= 2) pinned + device buffers of
+ * `slot_frames` (<= max_batch) frames each.  orbfe_stream_submit() enqueues upload, kernels and
+ * result download of one slot on three HIP streams and returns without waiting;
+ * orbfe_stream_collect() waits for the OLDEST submitted slot only and hands its results over.
+ * Upload of slot i+1, kernels of slot i and download of slot i-1 overlap.  Pinned sources with a
+ * 4-byte-aligned pitch are copied by the DMA engine straight from the caller's buffer; pageable
+ * ones are re-pitched into the slot's pinned block by a small thread pool first.
+ * Results are byte-identical to orbfe_extract_batch / orbfe_extract_batch_device.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orbfe_stream orbfe_stream;
+int orbfe_stream_create(orbfe_handle *h, int slots, int slot_frames, orbfe_stream **out);
+void orbfe_stream_destroy(orbfe_stream *s);
+/* enqueue `n` (1..slot_frames) frames; ORBFE_ERR_BUSY when `slots` submissions are uncollected */
+int orbfe_stream_submit(orbfe_stream *s, const uint8_t *const *grays, int pitch, int n);
+/* wait for the oldest submission; outputs as orbfe_extract_batch (strides cap / cap*32 / n_levels);
+ * *n_frames receives how many frames that submission held.  ORBFE_ERR_INVALID_ARG when nothing
+ * is in flight. */
+int orbfe_stream_collect(orbfe_stream *s, orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out,
+                         int *per_level_counts, int *n_frames);
+/* the same without the copy: pointers into the slot's pinned result block (frame b at the strides
+ * above), valid until the next orbfe_stream_submit() that reuses the slot (`slots` submissions
+ * later) */
+int orbfe_stream_collect_view(orbfe_stream *s, const orbfe_keypoint **kp, const uint8_t **desc,
+                              const int **n, const int **per_level_counts, int *n_frames);
+int orbfe_stream_in_flight(const orbfe_stream *s);
 
 /* replaces the public members mvImagePyramid / mvBlurredImagePyramid
  * (include/ORBextractor.h:94-95): copies level `level` of frame `frame` of the LAST extract call

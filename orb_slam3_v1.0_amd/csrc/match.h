@@ -12,6 +12,7 @@ struct MatchScratch {
     size_t dBytes = 0;
     void* hpin = nullptr;   // pinned host arena
     size_t hBytes = 0;
+    hipEvent_t busy = nullptr;  // recorded behind the last launch that used the arenas (owned by the handle)
 };
 
 void match_scratch_free(MatchScratch& m);

@@ -53,6 +53,8 @@ __device__ __forceinline__ void wave_top2(unsigned long long& k1, unsigned long 
 // grow-only arenas
 inline int ensure(MatchScratch& m, size_t dBytes, size_t hBytes, std::string& err)
 {
+    // an asynchronous *_device launch on another stream may still be using the arenas: wait before replacing them
+    if ((dBytes > m.dBytes || hBytes > m.hBytes) && m.busy && (m.d || m.hpin)) (void)hipEventSynchronize(m.busy);
     if (dBytes > m.dBytes) {
         if (m.d) (void)hipFree(m.d);
         m.d = nullptr;

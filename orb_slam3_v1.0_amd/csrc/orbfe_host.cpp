@@ -12,7 +12,10 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <condition_variable>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "launch.h"
@@ -95,6 +98,13 @@ struct orbfe_handle {
     MatchScratch match;
     std::mutex mu;
     std::string err;
+
+    // Cross-stream ordering of the scratch the handle owns: an event recorded behind the last enqueue that used the
+    // extraction scratch (pyramid, candidates, counters, level keypoints) / the matcher arena, and the stream it ran on.
+    // The next enqueue on a different stream waits for it first; the getters wait for it on the host.
+    hipEvent_t evExtract = nullptr, evMatch = nullptr;
+    hipStream_t extractStream = nullptr, matchStream = nullptr;
+    bool extractUsed = false, matchUsed = false;
 };
 
 namespace {
@@ -112,6 +122,36 @@ int fail_hip(orbfe_handle* h, hipError_t e, const char* what, int line)
         hipError_t e_ = (call);                                           \
         if (e_ != hipSuccess) return fail_hip((h), e_, #call, __LINE__);  \
     } while (0)
+
+// scratch hand-over between streams (see the handle): call with h->mu held
+int scratch_acquire(orbfe_handle* h, bool used, hipStream_t last, hipEvent_t ev, hipStream_t s)
+{
+    if (used && last != s) HIPCHK(h, hipStreamWaitEvent(s, ev, 0));
+    return ORBFE_OK;
+}
+
+int extract_scratch_release(orbfe_handle* h, hipStream_t s)
+{
+    HIPCHK(h, hipEventRecord(h->evExtract, s));
+    h->extractStream = s;
+    h->extractUsed = true;
+    return ORBFE_OK;
+}
+
+// RAII pair around a matcher launch: waits for the arena's previous user on another stream, records behind this one
+struct MatchScope {
+    orbfe_handle* h;
+    hipStream_t s;
+    int rc;
+    MatchScope(orbfe_handle* h_, hipStream_t s_) : h(h_), s(s_), rc(scratch_acquire(h_, h_->matchUsed, h_->matchStream, h_->evMatch, s_)) {}
+    ~MatchScope()
+    {
+        if (hipEventRecord(h->evMatch, s) == hipSuccess) {
+            h->matchStream = s;
+            h->matchUsed = true;
+        }
+    }
+};
 
 int cv_round_f(float v) { return (int)lrintf(v); }
 
@@ -137,6 +177,9 @@ void destroy_impl(orbfe_handle* h)
     for (auto& set : h->ev)
         for (auto& e : set)
             if (e) (void)hipEventDestroy(e);
+    if (h->evExtract) (void)hipEventDestroy(h->evExtract);
+    if (h->evMatch) (void)hipEventDestroy(h->evMatch);
+    h->match.busy = nullptr;
     match_scratch_free(h->match);
     for (auto& g : h->graphs)
         if (g.second) (void)hipGraphExecDestroy(g.second);
@@ -167,6 +210,7 @@ const char* orbfe_status_string(int s)
     case ORBFE_ERR_HIP: return "HIP runtime error";
     case ORBFE_ERR_OUT_OF_MEMORY: return "out of memory";
     case ORBFE_ERR_INTERNAL: return "internal device-side guard tripped";
+    case ORBFE_ERR_BUSY: return "every slot of the stream ring is in flight";
     default: return "unknown status";
     }
 }
@@ -366,6 +410,9 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     h->hKp = reinterpret_cast<orbfe_keypoint*>(h->hOutBlock + h->offKp);
     h->hDesc = h->hOutBlock + h->offDesc;
     h->useGraph = getenv("ORBFE_NO_GRAPH") == nullptr;
+    CREATE_CHK(hipEventCreateWithFlags(&h->evExtract, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&h->evMatch, hipEventDisableTiming));
+    h->match.busy = h->evMatch;  // the arena is not regrown while a launch still uses it
     for (auto& set : h->ev)
         for (auto& e : set) CREATE_CHK(hipEventCreate(&e));
 #undef CREATE_CHK
@@ -440,6 +487,8 @@ int orbfe_extract_batch_device(orbfe_handle* h, const uint8_t* d_gray, size_t fr
                                int batch, orbfe_keypoint* d_kp, uint8_t* d_desc, int* d_n, int* d_per,
                                void* stream_)
 {
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
     return extract_chain(h, d_gray, frame_stride, pitch, batch, d_kp, d_desc, d_n, d_per, nullptr, stream_);
 }
 
@@ -449,11 +498,21 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
                          orbfe_keypoint* d_kp, uint8_t* d_desc, int* d_n, int* d_per, int* d_status, void* stream_)
 {
     if (!h || !d_gray || !d_kp || !d_desc || !d_n) return ORBFE_ERR_INVALID_ARG;
-    if (batch < 1 || batch > h->maxBatch || pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
-    if (batch > 1 && frame_stride < (size_t)pitch * (h->prm.image_height - 1) + h->prm.image_width)
-        return ORBFE_ERR_INVALID_ARG;
+    if (batch < 1 || batch > h->maxBatch || pitch < h->prm.image_width || pitch >= (1 << 24)) return ORBFE_ERR_INVALID_ARG;
+    const int aligned4 = ((reinterpret_cast<uintptr_t>(d_gray) | (uintptr_t)pitch | (uintptr_t)frame_stride) & 3u) == 0;
+    // frame extent the kernels read (orbfe.h, input contract): whole dwords on the aligned path
+    const size_t rowEnd = aligned4 ? (size_t)((h->prm.image_width + 3) & ~3) : (size_t)h->prm.image_width;
+    if (batch > 1 && frame_stride < (size_t)pitch * (h->prm.image_height - 1) + rowEnd) return ORBFE_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
+    // while the chain is being captured into a hipGraph the hand-over events stay outside it: the replay path waits
+    // and records around hipGraphLaunch
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) (void)hipGetLastError();
+    if (capturing == hipStreamCaptureStatusNone) {
+        const int rc = scratch_acquire(h, h->extractUsed, h->extractStream, h->evExtract, s);
+        if (rc != ORBFE_OK) return rc;
+    }
     const PipelineDesc& P = h->P;
     const int nL = P.nLevels;
     hipEvent_t* ev = nullptr;
@@ -462,8 +521,6 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
         h->evHead = (h->evHead + 1) % kEventSets;
         h->evCount++;
     }
-    const int aligned4 = ((reinterpret_cast<uintptr_t>(d_gray) | (uintptr_t)pitch | (uintptr_t)frame_stride) & 3u) == 0;
-
     HIPCHK(h, hipMemsetAsync(h->dCounters, 0, (size_t)batch * nL * kCntWords * sizeof(uint32_t), s));
     if (ev) HIPCHK(h, hipEventRecord(ev[0], s));
     // ComputePyramid (:607-623): level l from the UNBLURRED level l-1
@@ -497,6 +554,7 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
     h->lastStride = frame_stride;
     h->lastPitch = pitch;
     h->lastBatch = batch;
+    if (capturing == hipStreamCaptureStatusNone) return extract_scratch_release(h, s);
     return ORBFE_OK;
 }
 
@@ -570,7 +628,15 @@ static int extract_enqueue_replay(orbfe_handle* h, int batch, int inPitch, hipSt
         }
         viaGraph = h->useGraph;  // capture may have failed: plain launches below
         if (viaGraph) {
+            {
+                const int rca = scratch_acquire(h, h->extractUsed, h->extractStream, h->evExtract, s);
+                if (rca != ORBFE_OK) return rca;
+            }
             HIPCHK(h, hipGraphLaunch(h->graphs[gkey], s));
+            {
+                const int rcr = extract_scratch_release(h, s);
+                if (rcr != ORBFE_OK) return rcr;
+            }
             h->lastGray = h->dIn;  // what extract_chain records on a plain launch (pyramid / candidate getters)
             h->lastStride = inFrame;
             h->lastPitch = inPitch;
@@ -644,14 +710,330 @@ int orbfe_extract(orbfe_handle* h, const uint8_t* gray, int pitch, orbfe_keypoin
     return orbfe_extract_batch(h, one, pitch, 1, kp_out, desc_out, n_out, per_level);
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined host-pointer extraction (orbfe.h: orbfe_stream_*)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// a few persistent workers for the row-by-row re-pitch of pageable frames into pinned memory (one thread moves
+// ~8 GB/s of 752-byte rows: a third of what the PCIe link takes)
+class RowCopyPool {
+public:
+    explicit RowCopyPool(int n)
+    {
+        for (int i = 0; i < n; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~RowCopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    // run fn(i) for i in [0, n) on the workers and the caller; returns when all are done
+    void parallel_for(int n, const std::function<void(int)>& fn)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            next_ = 0;
+            end_ = n;
+            pending_ = n;
+        }
+        cv_.notify_all();
+        run_some();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void run_some()
+    {
+        for (;;) {
+            int i;
+            const std::function<void(int)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!fn_ || next_ >= end_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || (fn_ && next_ < end_); });
+                if (stop_) return;
+            }
+            run_some();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, end_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+struct StreamSlot {
+    uint8_t* hIn = nullptr;   // pinned, slotFrames x inFrame
+    uint8_t* dIn = nullptr;
+    uint8_t* dOut = nullptr;  // [n | status | per-level | keypoints | descriptors], the handle's block layout
+    uint8_t* hOut = nullptr;  // pinned mirror
+    hipEvent_t evIn = nullptr, evDone = nullptr, evOut = nullptr;
+    int n = 0;
+};
+
+}  // namespace
+
+struct orbfe_stream {
+    orbfe_handle* h = nullptr;
+    int nSlots = 0, slotFrames = 0;
+    size_t inFrame = 0, outBytes = 0, offStatus = 0, offPer = 0, offKp = 0, offDesc = 0;
+    hipStream_t sIn = nullptr, sOut = nullptr;  // upload / download; the kernels run on the handle's stream
+    std::vector<StreamSlot> slots;
+    unsigned long long submitted = 0, collected = 0;
+    RowCopyPool* pool = nullptr;
+};
+
+extern "C" {
+
+void orbfe_stream_destroy(orbfe_stream* st)
+{
+    if (!st) return;
+    orbfe_handle* h = st->h;
+    (void)hipSetDevice(h->device);
+    if (st->sIn) (void)hipStreamSynchronize(st->sIn);
+    (void)hipStreamSynchronize(h->stream);
+    if (st->sOut) (void)hipStreamSynchronize(st->sOut);
+    for (auto& sl : st->slots) {
+        if (sl.hIn) (void)hipHostFree(sl.hIn);
+        if (sl.dIn) (void)hipFree(sl.dIn);
+        if (sl.dOut) (void)hipFree(sl.dOut);
+        if (sl.hOut) (void)hipHostFree(sl.hOut);
+        for (hipEvent_t e : {sl.evIn, sl.evDone, sl.evOut})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (st->sIn) (void)hipStreamDestroy(st->sIn);
+    if (st->sOut) (void)hipStreamDestroy(st->sOut);
+    delete st->pool;
+    delete st;
+}
+
+int orbfe_stream_create(orbfe_handle* h, int slots, int slot_frames, orbfe_stream** out)
+{
+    if (!h || !out || slots < 2 || slots > 64 || slot_frames < 1 || slot_frames > h->maxBatch) return ORBFE_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    orbfe_stream* st = new (std::nothrow) orbfe_stream();
+    if (!st) return ORBFE_ERR_OUT_OF_MEMORY;
+    st->h = h;
+    st->nSlots = slots;
+    st->slotFrames = slot_frames;
+    st->inFrame = (size_t)h->dInPitch * h->prm.image_height;
+    const size_t B = (size_t)slot_frames, cap = (size_t)h->P.kpCapFrame;
+    {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+        take(B * sizeof(int));
+        st->offStatus = take(B * sizeof(int));
+        st->offPer = take(B * h->nLevels * sizeof(int));
+        st->offKp = take(B * cap * sizeof(orbfe_keypoint));
+        st->offDesc = take(B * cap * ORBFE_DESC_BYTES);
+        st->outBytes = off;
+    }
+    st->slots.resize((size_t)slots);
+    bool ok = hipStreamCreateWithFlags(&st->sIn, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->sOut, hipStreamNonBlocking) == hipSuccess;
+    for (auto& sl : st->slots) {
+        ok = ok && hipHostMalloc(&sl.hIn, st->inFrame * B) == hipSuccess && hipMalloc(&sl.dIn, st->inFrame * B) == hipSuccess &&
+             hipMalloc(&sl.dOut, st->outBytes) == hipSuccess && hipHostMalloc(&sl.hOut, st->outBytes) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        h->err = "orbfe_stream_create: allocation failed";
+        orbfe_stream_destroy(st);
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    st->pool = new RowCopyPool((int)std::min<unsigned>(7u, hw > 2 ? hw / 2 : 1));
+    *out = st;
+    return ORBFE_OK;
+}
+
+int orbfe_stream_in_flight(const orbfe_stream* st) { return st ? (int)(st->submitted - st->collected) : 0; }
+
+int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch, int n)
+{
+    if (!st || !grays || n < 1 || n > st->slotFrames) return ORBFE_ERR_INVALID_ARG;
+    orbfe_handle* h = st->h;
+    if (pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
+    if (st->submitted - st->collected >= (unsigned long long)st->nSlots) return ORBFE_ERR_BUSY;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    StreamSlot& sl = st->slots[st->submitted % st->nSlots];
+    const int W = h->prm.image_width, H = h->prm.image_height;
+    // (the slot was collected: its previous upload, kernels and download have completed -- evOut was waited for)
+    bool direct = pitch <= h->dInPitch && (pitch & 3) == 0;
+    for (int b = 0; b < n; b++) {
+        if (!grays[b]) return ORBFE_ERR_INVALID_ARG;
+        if (direct) {
+            hipPointerAttribute_t attr;
+            if ((reinterpret_cast<uintptr_t>(grays[b]) & 3u) != 0 || hipPointerGetAttributes(&attr, grays[b]) != hipSuccess ||
+                attr.type != hipMemoryTypeHost) {
+                (void)hipGetLastError();
+                direct = false;
+            }
+        }
+    }
+    const int inPitch = direct ? pitch : h->dInPitch;
+    size_t frameStride = st->inFrame;
+    if (direct) {
+        // pinned sources: DMA straight from the caller's memory.  Frames that sit at a constant distance (a packed
+        // [n][H][pitch] block is the usual case) go as ONE copy and keep that distance on the device.
+        const size_t bytes = (size_t)pitch * (H - 1) + (size_t)((W + 3) & ~3);
+        bool block = n > 1 && grays[1] > grays[0];
+        const size_t dist = block ? (size_t)(grays[1] - grays[0]) : 0;
+        for (int b = 2; b < n && block; b++) block = grays[b] == grays[b - 1] + dist;
+        block = block && (dist & 3) == 0 && dist >= bytes && dist * (size_t)(n - 1) + bytes <= st->inFrame * (size_t)st->slotFrames;
+        if (block) {
+            frameStride = dist;
+            HIPCHK(h, hipMemcpyAsync(sl.dIn, grays[0], dist * (size_t)(n - 1) + bytes, hipMemcpyHostToDevice, st->sIn));
+        } else {
+            for (int b = 0; b < n; b++)
+                HIPCHK(h, hipMemcpyAsync(sl.dIn + b * st->inFrame, grays[b], std::min(bytes, st->inFrame), hipMemcpyHostToDevice, st->sIn));
+        }
+    } else {
+        const int dp = h->dInPitch;
+        const size_t inFrame = st->inFrame;
+        uint8_t* hIn = sl.hIn;
+        // 4 row bands per frame so that a handful of frames still spreads over the pool
+        const int bands = 4;
+        st->pool->parallel_for(n * bands, [&](int job) {
+            const int b = job / bands, band = job - b * bands;
+            const int y0 = H * band / bands, y1 = H * (band + 1) / bands;
+            for (int y = y0; y < y1; y++) memcpy(hIn + b * inFrame + (size_t)y * dp, grays[b] + (size_t)y * pitch, (size_t)W);
+        });
+        HIPCHK(h, hipMemcpyAsync(sl.dIn, sl.hIn, st->inFrame * (size_t)n, hipMemcpyHostToDevice, st->sIn));
+    }
+    HIPCHK(h, hipEventRecord(sl.evIn, st->sIn));
+    // kernels on the handle's stream, behind the upload
+    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.evIn, 0));
+    const int rc = extract_chain(h, sl.dIn, frameStride, inPitch, n, reinterpret_cast<orbfe_keypoint*>(sl.dOut + st->offKp),
+                                 sl.dOut + st->offDesc, reinterpret_cast<int*>(sl.dOut), reinterpret_cast<int*>(sl.dOut + st->offPer),
+                                 reinterpret_cast<int*>(sl.dOut + st->offStatus), h->stream);
+    if (rc != ORBFE_OK) return rc;
+    HIPCHK(h, hipEventRecord(sl.evDone, h->stream));
+    // download behind the kernels: the whole block for a full slot (one copy), the used parts otherwise
+    HIPCHK(h, hipStreamWaitEvent(st->sOut, sl.evDone, 0));
+    if (n == st->slotFrames) {
+        HIPCHK(h, hipMemcpyAsync(sl.hOut, sl.dOut, st->outBytes, hipMemcpyDeviceToHost, st->sOut));
+    } else {
+        const size_t cap = (size_t)h->P.kpCapFrame;
+        HIPCHK(h, hipMemcpyAsync(sl.hOut, sl.dOut, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st->sOut));
+        HIPCHK(h, hipMemcpyAsync(sl.hOut + st->offStatus, sl.dOut + st->offStatus, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st->sOut));
+        HIPCHK(h, hipMemcpyAsync(sl.hOut + st->offPer, sl.dOut + st->offPer, (size_t)n * h->nLevels * sizeof(int), hipMemcpyDeviceToHost, st->sOut));
+        HIPCHK(h, hipMemcpyAsync(sl.hOut + st->offKp, sl.dOut + st->offKp, (size_t)n * cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, st->sOut));
+        HIPCHK(h, hipMemcpyAsync(sl.hOut + st->offDesc, sl.dOut + st->offDesc, (size_t)n * cap * ORBFE_DESC_BYTES, hipMemcpyDeviceToHost, st->sOut));
+    }
+    HIPCHK(h, hipEventRecord(sl.evOut, st->sOut));
+    sl.n = n;
+    st->submitted++;
+    return ORBFE_OK;
+}
+
+// waits for the oldest submission and checks its guard flags; *slot_out stays in flight until the caller bumps `collected`
+static int stream_wait_oldest(orbfe_stream* st, StreamSlot** slot_out)
+{
+    if (!st || st->submitted == st->collected) return ORBFE_ERR_INVALID_ARG;
+    orbfe_handle* h = st->h;
+    StreamSlot& sl = st->slots[st->collected % st->nSlots];
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(sl.evOut));
+    *slot_out = &sl;
+    const int* status = reinterpret_cast<const int*>(sl.hOut + st->offStatus);
+    for (int b = 0; b < sl.n; b++)
+        if (status[b]) {
+            char buf[128];
+            snprintf(buf, sizeof buf, "device guard flags 0x%x at frame %d of the collected submission", (unsigned)status[b], b);
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->err = buf;
+            st->collected++;
+            return ORBFE_ERR_INTERNAL;
+        }
+    return ORBFE_OK;
+}
+
+int orbfe_stream_collect_view(orbfe_stream* st, const orbfe_keypoint** kp, const uint8_t** desc, const int** n,
+                              const int** per_level, int* n_frames)
+{
+    StreamSlot* sl = nullptr;
+    const int rc = stream_wait_oldest(st, &sl);
+    if (rc != ORBFE_OK) return rc;
+    if (kp) *kp = reinterpret_cast<const orbfe_keypoint*>(sl->hOut + st->offKp);
+    if (desc) *desc = sl->hOut + st->offDesc;
+    if (n) *n = reinterpret_cast<const int*>(sl->hOut);
+    if (per_level) *per_level = reinterpret_cast<const int*>(sl->hOut + st->offPer);
+    if (n_frames) *n_frames = sl->n;
+    st->collected++;
+    return ORBFE_OK;
+}
+
+int orbfe_stream_collect(orbfe_stream* st, orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, int* n_frames)
+{
+    if (!st || !kp_out || !desc_out || !n_out) return ORBFE_ERR_INVALID_ARG;
+    StreamSlot* sl = nullptr;
+    const int rc = stream_wait_oldest(st, &sl);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_handle* h = st->h;
+    const size_t cap = (size_t)h->P.kpCapFrame;
+    const int nL = h->nLevels;
+    const int* hn = reinterpret_cast<const int*>(sl->hOut);
+    const orbfe_keypoint* hkp = reinterpret_cast<const orbfe_keypoint*>(sl->hOut + st->offKp);
+    const uint8_t* hdesc = sl->hOut + st->offDesc;
+    const int* hper = reinterpret_cast<const int*>(sl->hOut + st->offPer);
+    const int nfr = sl->n;
+    st->pool->parallel_for(nfr, [&](int b) {
+        const int k = hn[b];
+        n_out[b] = k;
+        memcpy(kp_out + b * cap, hkp + b * cap, (size_t)k * sizeof(orbfe_keypoint));
+        memcpy(desc_out + b * cap * ORBFE_DESC_BYTES, hdesc + b * cap * ORBFE_DESC_BYTES, (size_t)k * ORBFE_DESC_BYTES);
+        if (per_level) memcpy(per_level + (size_t)b * nL, hper + (size_t)b * nL, nL * sizeof(int));
+    });
+    if (n_frames) *n_frames = nfr;
+    st->collected++;
+    return ORBFE_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 int orbfe_get_pyramid_level(orbfe_handle* h, int frame, int level, int blurred, uint8_t* out, int out_pitch)
 {
-    if (!h || !out || level < 0 || level >= h->nLevels || frame < 0 || frame >= h->lastBatch) return ORBFE_ERR_INVALID_ARG;
+    if (!h || !out || level < 0 || level >= h->nLevels || frame < 0) return ORBFE_ERR_INVALID_ARG;
     const LevelDesc& L = h->P.lv[level];
     if (out_pitch < L.w) return ORBFE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (frame >= h->lastBatch) return ORBFE_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->extractUsed) HIPCHK(h, hipEventSynchronize(h->evExtract));  // the last call, whatever stream it ran on
     const uint8_t* src;
     size_t spitch;
     if (blurred) {
@@ -671,10 +1053,11 @@ int orbfe_get_pyramid_level(orbfe_handle* h, int frame, int level, int blurred, 
 int orbfe_debug_get_candidates(orbfe_handle* h, int frame, int level, uint32_t* packed, int cap, int* n_out,
                                int counters[4])
 {
-    if (!h || !n_out || level < 0 || level >= h->nLevels || frame < 0 || frame >= h->lastBatch) return ORBFE_ERR_INVALID_ARG;
+    if (!h || !n_out || level < 0 || level >= h->nLevels || frame < 0) return ORBFE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (frame >= h->lastBatch) return ORBFE_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->extractUsed) HIPCHK(h, hipEventSynchronize(h->evExtract));
     uint32_t c[kCntWords];
     HIPCHK(h, hipMemcpy(c, h->dCounters + ((size_t)frame * h->nLevels + level) * kCntWords, sizeof c, hipMemcpyDeviceToHost));
     const LevelDesc& L = h->P.lv[level];
@@ -690,6 +1073,28 @@ int orbfe_debug_get_candidates(orbfe_handle* h, int frame, int level, uint32_t* 
         HIPCHK(h, hipMemcpy(packed, h->dCand + L.candOff + (size_t)frame * L.candCap, (size_t)m * sizeof(uint32_t),
                             hipMemcpyDeviceToHost));
     *n_out = m;
+    return ORBFE_OK;
+}
+
+int orbfe_get_device_status(orbfe_handle* h, unsigned* flags_out)
+{
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned flags = 0;
+    if (h->extractUsed && h->lastBatch > 0) {
+        HIPCHK(h, hipEventSynchronize(h->evExtract));
+        std::vector<uint32_t> c((size_t)h->lastBatch * h->nLevels * kCntWords);
+        HIPCHK(h, hipMemcpy(c.data(), h->dCounters, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < (size_t)h->lastBatch * h->nLevels; i++) flags |= c[i * kCntWords + kCntStatus];
+    }
+    if (flags_out) *flags_out = flags;
+    if (flags) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "device guard flags 0x%x in the last extract call", flags);
+        h->err = buf;
+        return ORBFE_ERR_INTERNAL;
+    }
     return ORBFE_OK;
 }
 
@@ -715,6 +1120,8 @@ int orbfe_match_projection(orbfe_handle* h, const orbfe_frame_view* F, int M, co
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     int rc = match_projection_run(h->match, h->stream, F, M, mps, mp_desc, init_obs, th, far_points, th_far, nn_ratio,
                                   match_out, n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
@@ -735,6 +1142,8 @@ int orbfe_match_projection_batch_device(orbfe_handle* h, int batch, const orbfe_
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
     std::string err;
+    MatchScope scope_(h, s);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     int rc = match_projection_batch_device(h->match, s, batch, d_kp, d_desc, d_n, kp_stride, grid_cols, grid_rows, min_x,
                                            min_y, inv_w, inv_h, h->dSf, h->nLevels, M, d_mps, d_mp_desc, d_init_obs, th,
                                            far_points, th_far, nn_ratio, d_match_out, d_n_matches, err);
@@ -752,6 +1161,8 @@ int orbfe_match_initialization(orbfe_handle* h, const orbfe_frame_view* F1, cons
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     int rc = match_initialization_run(h->match, h->stream, F1, F2, window_size, nn_ratio, check_orientation, matches12_out,
                                       n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
@@ -784,6 +1195,8 @@ int orbfe_project_map_points(orbfe_handle* h, const orbfe_frustum* frustum, int 
     // staging through the matcher's grow-only arenas: [points | out | xr] on both sides
     const size_t bIn = (size_t)n * sizeof(orbfe_world_point), bOut = (size_t)n * sizeof(orbfe_map_point), bXr = (size_t)n * sizeof(float);
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     int rc = ensure(h->match, bIn + bOut + bXr + 256, bIn + bOut + bXr + 256, err);
     if (rc != ORBFE_OK) {
         h->err = err;
@@ -818,6 +1231,8 @@ int orbfe_fuse_search(orbfe_handle* h, const orbfe_frame_view* KF, const float* 
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     const int rc = fuse_search_run(h->match, h->stream, KF, inv_level_sigma2, u_right, frustum, th, M, points, mp_desc, 1,
                                    best_idx_out, best_dist_out, err);
     if (rc != ORBFE_OK) h->err = err;
@@ -839,6 +1254,8 @@ int orbfe_fuse_search_sim3(orbfe_handle* h, const orbfe_frame_view* KF, const or
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     const int rc = fuse_search_run(h->match, h->stream, KF, nullptr, nullptr, frustum, th, M, points, mp_desc, 0,
                                    best_idx_out, best_dist_out, err);
     if (rc != ORBFE_OK) h->err = err;
@@ -861,6 +1278,8 @@ int orbfe_search_by_sim3(orbfe_handle* h, const orbfe_frame_view* KF1, const orb
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     const int rc = search_by_sim3_run(h->match, h->stream, KF1, KF2, dir12, dir21, mp1, mp_desc1, mp2, mp_desc2, th,
                                       match12_out, n_found, err);
     if (rc != ORBFE_OK) h->err = err;
@@ -880,6 +1299,8 @@ int orbfe_match_projection_keyframe(orbfe_handle* h, const orbfe_frame_view* fra
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     const int rc = match_projection_kf_run(h->match, h->stream, frame, frustum, n_points, points, mp_desc, kf_angle,
                                            frame_has_mp, th, check_orientation, match_out, n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
@@ -901,6 +1322,8 @@ int orbfe_match_triangulation(orbfe_handle* h, int n_groups, const int* kf1_off,
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     const int rc = match_triangulation_run(h->match, h->stream, n_groups, kf1_off, kf1_idx, kf2_off, kf2_idx, n1, kp1, desc1,
                                            has_mp1, stereo1, n2, kp2, desc2, has_mp2, stereo2, scale_factors2, n_levels2,
                                            params, matches12_out, n_matches, err);
@@ -917,6 +1340,8 @@ int orbfe_distinctive_descriptors(orbfe_handle* h, int n_sets, const int* set_of
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     const int rc = distinctive_run(h->match, h->stream, n_sets, set_off, desc, best_idx_out, best_median_out, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
@@ -1131,6 +1556,8 @@ int orbfe_match_bow(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
     int rc = match_bow_run(h->match, h->stream, G, kf_off, kf_idx, f_off, f_idx, n_kf, kf_desc, kf_angle, kf_has_mp, n_f,
                            f_desc, f_angle, nn_ratio, check_orientation, match_out, n_matches, err);
     if (rc != ORBFE_OK) h->err = err;

@@ -24,7 +24,8 @@ WP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("min_distance", 
 NUM_STAGES = 5
 
 STATUS = {0: "ORBFE_OK", 1: "ORBFE_ERR_INVALID_ARG", 2: "ORBFE_ERR_UNSUPPORTED", 3: "ORBFE_ERR_NO_DEVICE",
-          4: "ORBFE_ERR_HIP", 5: "ORBFE_ERR_OUT_OF_MEMORY", 6: "ORBFE_ERR_INTERNAL"}
+          4: "ORBFE_ERR_HIP", 5: "ORBFE_ERR_OUT_OF_MEMORY", 6: "ORBFE_ERR_INTERNAL", 7: "ORBFE_ERR_BUSY"}
+ERR_BUSY = 7
 
 
 class OrbfeError(RuntimeError):
@@ -79,6 +80,8 @@ SYMBOLS = [
     "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
     "orbfe_prep_create", "orbfe_prep_destroy", "orbfe_prepare_image", "orbfe_prepare_image_device", "orbfe_prepare_and_extract",
     "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_get_device_status", "orbfe_stream_create", "orbfe_stream_destroy", "orbfe_stream_submit", "orbfe_stream_collect",
+    "orbfe_stream_collect_view", "orbfe_stream_in_flight",
 ]
 
 _lib = None
@@ -123,6 +126,14 @@ def lib():
     L.orbfe_max_keypoints.argtypes = [vp]
     L.orbfe_extract.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.orbfe_extract_batch.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    L.orbfe_get_device_status.argtypes = [vp, vp]
+    L.orbfe_stream_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    L.orbfe_stream_destroy.argtypes = [vp]
+    L.orbfe_stream_destroy.restype = None
+    L.orbfe_stream_submit.argtypes = [vp, vp, ci, ci]
+    L.orbfe_stream_collect.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orbfe_stream_collect_view.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orbfe_stream_in_flight.argtypes = [vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, sz, ci, ci, vp, vp, vp, vp, vp]
     L.orbfe_get_pyramid_level.argtypes = [vp, ci, ci, ci, vp, ci]
     L.orbfe_debug_get_candidates.argtypes = [vp, ci, ci, vp, ci, vp, vp]
@@ -263,6 +274,16 @@ class ORBextractor:
                                                     d_desc_ptr, d_n_ptr, d_per_ptr, stream),
                   "orbfe_extract_batch_device")
 
+    def device_status(self):
+        """Guard flags of the last extract call on any stream (waits for it); raises when one is set."""
+        flags = C.c_uint()
+        self._chk(self.L.orbfe_get_device_status(self.h, C.byref(flags)), "orbfe_get_device_status")
+        return flags.value
+
+    def stream(self, slots=3, slot_frames=None):
+        """Pipelined host-pointer extraction (orbfe_stream_*): see ExtractStream."""
+        return ExtractStream(self, slots, slot_frames or self.max_batch)
+
     # mvImagePyramid / mvBlurredImagePyramid (include/ORBextractor.h:94-95)
     def pyramid_level(self, level, blurred=False, frame=0):
         w, h = int(self.levelW[level]), int(self.levelH[level])
@@ -301,6 +322,64 @@ def make_frame_view(kp, desc, gridCols, gridRows, minX, minY, maxX, maxY, scaleF
                    float(invh), len(sf), sf.ctypes.data)
     fv._keep = (kp, desc, sf)
     return fv
+
+
+class ExtractStream:
+    """orbfe_stream_*: a ring of pinned + device slots; submit() enqueues upload, kernels and download of up to
+    `slot_frames` frames without waiting, collect() waits for the oldest submission only."""
+
+    def __init__(self, ex, slots, slot_frames):
+        self.ex, self.L = ex, ex.L
+        self.slot_frames = slot_frames
+        h = C.c_void_p()
+        ex._chk(self.L.orbfe_stream_create(ex.h, slots, slot_frames, C.byref(h)), "orbfe_stream_create")
+        self.h = h
+        cap, nl = ex.cap, ex.nlevels
+        self._kp = np.zeros((slot_frames, cap), KP_DTYPE)
+        self._desc = np.zeros((slot_frames, cap, 32), np.uint8)
+        self._n = np.zeros(slot_frames, np.int32)
+        self._per = np.zeros((slot_frames, nl), np.int32)
+
+    def close(self):
+        if self.h:
+            self.L.orbfe_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def in_flight(self):
+        return self.L.orbfe_stream_in_flight(self.h)
+
+    def submit_ptrs(self, ptrs, pitch, n):
+        """ptrs: ctypes array of `n` host frame addresses; returns False when every slot is in flight."""
+        rc = self.L.orbfe_stream_submit(self.h, ptrs, pitch, n)
+        if rc == ERR_BUSY:
+            return False
+        self.ex._chk(rc, "orbfe_stream_submit")
+        return True
+
+    def submit(self, frames, pitch=None):
+        """frames: [n][H][W] uint8 array (numpy, or anything exposing ctypes data) in host memory."""
+        n = len(frames)
+        base = frames.ctypes.data
+        stride = frames.strides[0]
+        ptrs = (C.c_void_p * n)(*[base + b * stride for b in range(n)])
+        return self.submit_ptrs(ptrs, pitch or frames.strides[1], n)
+
+    def collect_raw(self):
+        """Results of the oldest submission in the stream's own arrays (overwritten by the next collect)."""
+        nf = C.c_int()
+        self.ex._chk(self.L.orbfe_stream_collect(self.h, _p(self._kp), _p(self._desc), _p(self._n), _p(self._per), C.byref(nf)),
+                     "orbfe_stream_collect")
+        return nf.value, self._kp, self._desc, self._n, self._per
+
+    def collect(self):
+        nf, kp, desc, n, per = self.collect_raw()
+        return [(kp[b, :n[b]].copy(), desc[b, :n[b]].copy(), per[b].copy()) for b in range(nf)]
 
 
 class ORBmatcher:

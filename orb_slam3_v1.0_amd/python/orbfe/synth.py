@@ -60,3 +60,28 @@ def stream(w, h, count, index0=0, density=0.0015):
 
 def batch(w, h, count, index0=0, density=0.0015):
     return np.stack([frame(w, h, index0 + i, density) for i in range(count)])
+
+
+def _pink(w, h, rng, sigma=40.0):
+    """1/f ("pink") noise canvas: random phases, amplitude 1 / spatial frequency -- texture at every scale."""
+    fy = np.fft.fftfreq(h)[:, None]
+    fx = np.fft.rfftfreq(w)[None, :]
+    f = np.sqrt(fx * fx + fy * fy)
+    f[0, 0] = 1.0
+    spec = (rng.standard_normal((h, w // 2 + 1)) + 1j * rng.standard_normal((h, w // 2 + 1))) / f
+    spec[0, 0] = 0.0
+    img = np.fft.irfft2(spec, s=(h, w))
+    img = img / img.std() * sigma + 128.0
+    return np.clip(np.rint(img), 0, 255).astype(np.int32)
+
+
+def pink_stream(w, h, count, index0=0):
+    """Like stream(), on a 1/f-noise scene (texture-rich: many weak corners at every pyramid level)."""
+    rng = np.random.default_rng(SEED0 + 104729 * (index0 + 1))
+    pad = 64
+    big = _pink(w + 2 * pad, h + 2 * pad, rng)
+    ox, oy = pad, pad
+    for _ in range(count):
+        yield _noise(big[oy:oy + h, ox:ox + w], rng)
+        ox = min(max(ox + int(rng.integers(-4, 5)), 0), 2 * pad)
+        oy = min(max(oy + int(rng.integers(-4, 5)), 0), 2 * pad)

@@ -88,3 +88,75 @@ def test_shard_gather_world2():
     for fidx, kb, db in res:
         k, d, _ = e.extract(synth.frame(128, 96, fidx))
         assert kb == k.tobytes() and db == d.tobytes()
+
+
+def _runner_worker(rank, world, port, out_q):
+    """bench.py's own per-step code (StepRunner: buffer rotation, packing, all_gather_into_tensor, rank-major layout)
+    under gloo on CPU, with a stub in place of the HIP extractor / matcher."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from orbfe.shard import shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, cap, nl = 5, 7, 3                       # strong scaling as in BASELINE config 4: 5 frames over 2 ranks (3 + 2)
+    lo, hi = shard_range(total, rank, world)
+    B, Bpad = hi - lo, (total + world - 1) // world
+    calls = []
+
+    def extract_fn(b, fs):                          # frame g of frame set fs -> n = g + 1 keypoints whose bytes encode (g, fs, slot)
+        calls.append(fs)
+        for j in range(B):
+            g = lo + j
+            b["n"][j] = g + 1
+            for k in range(g + 1):
+                b["kp"][j, k] = (g * 16 + fs * 4 + k) % 251
+                b["desc"][j, k] = (g + 2 * k + fs) % 253
+
+    def match_fn(b, fs):
+        for j in range(B):
+            b["match"][j, :lo + j + 1] = torch.arange(lo + j + 1, dtype=torch.int32) + 100 * (lo + j) + fs
+            b["nmatch"][j] = lo + j + 1
+
+    r = bench.StepRunner(torch.device("cpu"), Bpad, cap, nl, extract_fn, match_fn, dist, world, True, True, frame_sets=2)
+    for _ in range(3):
+        r.step()
+    assert calls == [0, 1, 0]                       # the steps rotate through the frame sets
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out_q.put((r.g_out.numpy().copy(), r.g_n.numpy().copy(), float(t.item()), Bpad, cap))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_runner_gloo_world2():
+    from orbfe.shard import shard_range, unpack_results
+    import oracle_py as O
+    world, total = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_runner_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    g_out, g_n, tmax, Bpad, cap = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tmax == 2.0
+    g_out = g_out.reshape(world, Bpad, cap, 60)
+    g_n = g_n.reshape(world, Bpad)
+    fs = 0  # the third step used frame set 0
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        kp, desc, match = unpack_results(g_out[r], O.KP_DTYPE)
+        for j in range(hi - lo):
+            g = lo + j
+            assert g_n[r, j] == g + 1
+            for k in range(g + 1):
+                assert (kp[j, k].tobytes() == bytes([(g * 16 + fs * 4 + k) % 251]) * 24)
+                assert (desc[j, k] == (g + 2 * k + fs) % 253).all()
+                assert match[j, k] == k + 100 * g + fs
+        for j in range(hi - lo, Bpad):  # padding slots of the short shard stay empty
+            assert g_n[r, j] == 0
