@@ -674,10 +674,16 @@ __global__ __launch_bounds__(256) void proj_topk_wave_kernel(ProjArgs A, int mpw
 // up to kResN keypoints), so sweeps and the exact rescans of starved map points never touch global memory.
 constexpr int kResN = 2048;
 
-struct ResolveLds {
-    int claim[kResN];                     // by rank
-    uint8_t oct[kResN];                   // by rank
-    int4 rec[kResN];                      // by storage slot: {rank, octave | cell y << 8, x bits, y bits}
+constexpr int kResNDesc = 1280;  // frames up to this many keypoints also keep their descriptors in LDS (77 KB per block)
+
+template <int N, bool DESC>
+struct ResolveLdsT {
+    int claim[3][N];                      // by rank; three rotating tables (final / this sweep / next sweep)
+    uint8_t oct[N];                       // by rank
+    int4 rec[N];                          // by storage slot: {rank, octave | cell y << 8, x bits, y bits}
+    // descriptors by storage slot: the exact rescans of starved map points (hundreds per frame when many map points
+    // compete for look-alike keypoints) then never wait on global memory
+    unsigned long long desc[DESC ? N * 4 : 4];
 };
 
 __device__ __forceinline__ void wave_top2_u32(uint32_t& k1, uint32_t& k2)
@@ -694,9 +700,9 @@ __device__ __forceinline__ void wave_top2_u32(uint32_t& k1, uint32_t& k2)
 // exact rescan for a map point whose stored top-K ran dry: one WAVE scans the contiguous rank range of the
 // window's grid columns (lane-strided) and reduces the two smallest free keys; all lanes get the result.
 // The claim test goes first: a starved map point sits in a region where nearly everything is taken.
-template <bool LDS>
+template <bool LDS, bool DESC, typename SLds>
 __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, int i, const int* claim,
-                                                    const ResolveLds* S, int lane, uint32_t& k1, uint32_t& k2)
+                                                    const SLds* S, int lane, uint32_t& k1, uint32_t& k2)
 {
     const MpWindow w = mp_window(A, A.mps[(size_t)f * A.M + i]);
     k1 = kKey32None;
@@ -722,8 +728,9 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
                 const float dx = __int_as_float(q.z) - w.x, dy = __int_as_float(q.w) - w.y;
                 if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;
                 int dist;
-                // descriptors of the few survivors come from L2: keeping them in LDS would take 64 KB per block
-                dist = hamming256(reinterpret_cast<const uint2*>(descS + (size_t)p * 4), d4);
+                // descriptors of the few survivors: from the block's LDS image when the frame is small enough for it, else L2
+                if constexpr (DESC) dist = hamming256(reinterpret_cast<const uint2*>(S->desc + (size_t)p * 4), d4);
+                else dist = hamming256(reinterpret_cast<const uint2*>(descS + (size_t)p * 4), d4);
                 if (dist >= A.dCut) continue;
                 const uint32_t key = make_key32(dist, q.x);
                 if (key < k1) { k2 = k1; k1 = key; }
@@ -736,28 +743,39 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
 
 // THREADS: 1024 for small launches (fewest ordered chunks: shortest call); 256 when the chip is full anyway -- a 1024-thread
 // block with its register and LDS footprint keeps a whole CU to itself while it mostly waits on barriers.
-template <bool LDS, int THREADS>
+template <bool LDS, int THREADS, int N = kResN, bool DESC = false>
 __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
 {
-    __shared__ ResolveLds S;
-    __shared__ int sChanged;
+    __shared__ ResolveLdsT<N, DESC> S;
+    __shared__ int sChanged[2];
     __shared__ int sCount;
-    __shared__ int sFbCount;                             // starved map points of the current sweep
+    __shared__ int sFbCount[2];                          // starved map points of the current sweep (by sweep parity, like sChanged)
     __shared__ int sFbMp[THREADS];
     __shared__ uint32_t sFbK1[THREADS], sFbK2[THREADS];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     const int n = min(A.nKp[f], A.kpStride);
     const int M = A.M;
-    int* claim = LDS ? S.claim : A.claimG + (size_t)f * A.kpStride;
+    // Claim tables (by rank): value = -1 if the slot holds a map point with observations on entry (:77-79), else the
+    // smallest accepted map point (with observations) whose best match is that keypoint, else kClaimFree.
+    // Three tables rotate so that a sweep needs TWO block barriers instead of five: T[fin] holds the final claims of
+    // the earlier chunks; T[cur] = T[fin] + the tentative claims of this sweep (written by atomicMin in phase 1, read
+    // in phase 2); T[nxt] is refilled with a copy of T[fin] during phase 2 for the next sweep.  A chunk that has
+    // converged promotes T[cur] to final.
+    int* T[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) T[q] = LDS ? S.claim[q] : A.claimG + ((size_t)f * 3 + q) * A.kpStride;
+    int fin = 0, cur = 1, nxt = 2;
     const orbfe_map_point* mps = A.mps + (size_t)f * M;
     const int* order = A.order + (size_t)f * A.kpStride;
     const int4* rec = A.rec + (size_t)f * A.kpStride;
     const int* initObs = A.initObs ? A.initObs + (size_t)f * A.kpStride : nullptr;
 
-    // claim[rank] = -1 if the slot holds a map point with observations on entry (:77-79); later the
-    // smallest accepted map point (with observations) whose best match is that keypoint
-    for (int r = tid; r < n; r += THREADS) claim[r] = (initObs && initObs[order[r]] > 0) ? -1 : kClaimFree;
+    for (int r = tid; r < n; r += THREADS) {
+        const int v = (initObs && initObs[order[r]] > 0) ? -1 : kClaimFree;
+        T[fin][r] = v;
+        T[cur][r] = v;
+    }
     const uint8_t* octByRank = A.octByRank + (size_t)f * A.kpStride;
     if constexpr (LDS) {
         for (int r = tid; r < n; r += THREADS) {
@@ -765,9 +783,13 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
             S.oct[r] = octByRank[r];
         }
     }
+    if constexpr (DESC) {
+        const unsigned long long* dsrc = A.descS + (size_t)f * A.kpStride * 4;
+        for (int q = tid; q < n * 4; q += THREADS) S.desc[q] = dsrc[q];
+    }
     if (tid == 0) sCount = 0;
     int nAccepted = 0;
-    __syncthreads();  // claim table and LDS image complete before the first sweep
+    __syncthreads();  // claim tables and LDS image complete before the first sweep
 
     for (int chunk = 0; chunk < M; chunk += THREADS) {
         const int i = chunk + tid;
@@ -789,17 +811,14 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
             }
         }
         int res = -1;  // rank of the accepted keypoint
+        // (T[cur] == T[fin] here: initialised above / refilled at the end of the previous chunk)
         for (int iter = 0; iter <= THREADS + 1; iter++) {
-            // (the barrier that ends the previous sweep -- or the one before the chunk loop -- orders this sweep's claim
-            // edits after every earlier read of the table)
-            // drop the tentative claims of this chunk (entries >= chunk), keep earlier chunks' final ones
-            for (int k = tid; k < n; k += THREADS)
-                if (claim[k] >= chunk) claim[k] = kClaimFree;
+            // ---- phase 1: this sweep's tentative claims on top of the final ones ----
+            if (tid == 0) { sChanged[iter & 1] = 0; sFbCount[iter & 1] = 0; }  // last read two barriers ago
+            if (res >= 0 && obs > 0) atomicMin(&T[cur][res], i);
             __syncthreads();
-            if (tid == 0) { sChanged = 0; sFbCount = 0; }  // every thread has read the previous sweep's sChanged by now
-            if (res >= 0 && obs > 0) atomicMin(&claim[res], i);
-            __syncthreads();
-            int result = -1;
+            // ---- phase 2: every map point of the chunk looks for its two best free candidates ----
+            const int* claim = T[cur];
             uint32_t k1 = kKey32None, k2 = kKey32None;
             int slot = -1;
             if (c > 0) {
@@ -826,49 +845,78 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
                         if (decided) k2 = keys[kTopK - 1];  // stand-in with distance dK: same verdict as the true second
                     }
                     if (!decided) {  // exact rescan, done cooperatively below
-                        slot = atomicAdd(&sFbCount, 1);
+                        slot = atomicAdd(&sFbCount[iter & 1], 1);
                         sFbMp[slot] = i;
                         atomicAdd(&A.dbg[f * 4 + 1], 1);
                     }
                 }
             }
-            __syncthreads();
-            {
-                const int nFb = sFbCount;  // block-uniform
-                if (nFb > 0) {
-                    for (int q = tid >> 6; q < nFb; q += THREADS / 64) {  // one wave per starved map point
-                        uint32_t a1, a2;
-                        full_scan_top2_wave<LDS>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
-                        if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
+            // the table of the next sweep starts as a copy of the final claims (nobody reads or writes T[nxt] in this phase)
+            for (int k = tid; k < n; k += THREADS) T[nxt][k] = T[fin][k];
+            auto verdict = [&]() {
+                int result = -1;
+                if (k1 != kKey32None) {
+                    const int bestDist = (int)(k1 >> kRankBits), bestRank = (int)(k1 & kRankMask);
+                    int bestLevel;
+                    if constexpr (LDS) bestLevel = S.oct[bestRank];
+                    else bestLevel = octByRank[bestRank];
+                    int bestDist2 = 256, bestLevel2 = -1;
+                    if (k2 != kKey32None) {
+                        bestDist2 = (int)(k2 >> kRankBits);
+                        const int r2 = (int)(k2 & kRankMask);
+                        if constexpr (LDS) bestLevel2 = S.oct[r2];
+                        else bestLevel2 = octByRank[r2];
                     }
-                    __syncthreads();
+                    if (bestDist <= ORBFE_TH_HIGH) {  // :108-117
+                        const bool reject = bestLevel == bestLevel2 && (float)bestDist > A.nnRatio * (float)bestDist2;
+                        if (!reject) result = bestRank;
+                    }
                 }
-            }
-            if (slot >= 0) { k1 = sFbK1[slot]; k2 = sFbK2[slot]; }
-            if (k1 != kKey32None) {
-                const int bestDist = (int)(k1 >> kRankBits), bestRank = (int)(k1 & kRankMask);
-                int bestLevel;
-                if constexpr (LDS) bestLevel = S.oct[bestRank];
-                else bestLevel = octByRank[bestRank];
-                int bestDist2 = 256, bestLevel2 = -1;
-                if (k2 != kKey32None) {
-                    bestDist2 = (int)(k2 >> kRankBits);
-                    const int r2 = (int)(k2 & kRankMask);
-                    if constexpr (LDS) bestLevel2 = S.oct[r2];
-                    else bestLevel2 = octByRank[r2];
+                return result;
+            };
+            if (slot < 0) {
+                const int result = verdict();
+                if (result != res) {
+                    res = result;
+                    sChanged[iter & 1] = 1;
                 }
-                if (bestDist <= ORBFE_TH_HIGH) {  // :108-117
-                    const bool reject = bestLevel == bestLevel2 && (float)bestDist > A.nnRatio * (float)bestDist2;
-                    if (!reject) result = bestRank;
-                }
-            }
-            if (result != res) {
-                res = result;
-                sChanged = 1;
             }
             __syncthreads();
+            if (sFbCount[iter & 1] > 0) {  // block-uniform, rare: some stored list ran dry undecided -- exact rescan, one wave per map point
+                const int nFb = sFbCount[iter & 1];
+                for (int q = tid >> 6; q < nFb; q += THREADS / 64) {
+                    uint32_t a1, a2;
+                    full_scan_top2_wave<LDS, DESC>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
+                    if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
+                }
+                __syncthreads();
+                if (slot >= 0) {
+                    k1 = sFbK1[slot];
+                    k2 = sFbK2[slot];
+                    const int result = verdict();
+                    if (result != res) {
+                        res = result;
+                        sChanged[iter & 1] = 1;
+                    }
+                }
+                __syncthreads();
+            }
             if (tid == 0) atomicAdd(&A.dbg[f * 4 + 0], 1);
-            if (!sChanged) break;
+            if (!sChanged[iter & 1]) break;  // fixed point: T[cur] = final claims + this chunk's
+            // next sweep writes its claims into the fresh copy
+            const int tq = cur;
+            cur = nxt;
+            nxt = tq;
+        }
+        // the converged table becomes the final one; the next chunk starts from a copy of it
+        {
+            const int tq = fin;
+            fin = cur;
+            cur = tq;
+        }
+        if (chunk + THREADS < M) {
+            for (int k = tid; k < n; k += THREADS) T[cur][k] = T[fin][k];
+            __syncthreads();
         }
         // F->mvpMapPoints[bestIdx] = pMP in map-point order: the last writer wins; nmatches counts accepts
         if (res >= 0) {
@@ -932,7 +980,7 @@ int proj_setup(MatchScratch& m, ProjArgs& A, Carver sc, size_t hostNeed, std::st
     const size_t oCol = sc.take((size_t)B * A.tabLevels * ((size_t)A.g.cols + 1) * sizeof(int));
     const size_t oCnt = sc.take((size_t)B * std::max(M, 1) * sizeof(int));
     const size_t oTopk = sc.take((size_t)B * kTopK * std::max(M, 1) * sizeof(uint32_t));
-    const size_t oClaim = sc.take((size_t)B * A.kpStride * sizeof(int));
+    const size_t oClaim = sc.take((size_t)B * 3 * A.kpStride * sizeof(int));  // three rotating claim tables per frame
     const size_t oPerm = sc.take((size_t)B * std::max(M, 1) * sizeof(int));
     const size_t oDbg = sc.take((size_t)B * 4 * sizeof(int));
     if (endOff) *endOff = sc.off;
@@ -983,7 +1031,14 @@ int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
             hipLaunchKernelGGL(proj_topk_wave_kernel<false>, grid, dim3(256), 0, s, A, mpw);
     }
     const bool lds = A.kpStride <= kResN;  // nKp[f] <= kpStride: the whole frame fits the LDS image
-    if (A.B >= 128) {
+    // Block shape of the resolve pass: a frame is a dependent chain of sweeps, so the call is shortest with the fewest
+    // chunks (1024 threads).  Frames of up to kResNDesc keypoints also stage their descriptors in LDS: the exact rescans
+    // of starved map points (one wave each, ~250 per frame on the bench stream) then run out of LDS on all 16 waves.
+    static const int envT = getenv("ORBFE_RESOLVE_THREADS") ? atoi(getenv("ORBFE_RESOLVE_THREADS")) : 0;  // tuning experiments
+    const int rt = envT ? envT : kResolveThreads;
+    if (lds && A.kpStride <= kResNDesc && rt == kResolveThreads) {
+        hipLaunchKernelGGL((proj_resolve_kernel<true, kResolveThreads, kResNDesc, true>), dim3(A.B), dim3(kResolveThreads), 0, s, A);
+    } else if (rt == 256) {
         if (lds) hipLaunchKernelGGL((proj_resolve_kernel<true, 256>), dim3(A.B), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((proj_resolve_kernel<false, 256>), dim3(A.B), dim3(256), 0, s, A);
     } else {
