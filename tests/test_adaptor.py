@@ -17,6 +17,32 @@ def _build():
                            "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"])
 
 
+BIN_CV = os.path.join(ROOT, "tests", "cpp", "test_adaptor_opencv.bin")
+
+
+def _build_cv():
+    """the ORBFE_WITH_OPENCV branch (exact reference signatures) against tests/cpp/mock_opencv: OpenCV is not in the image"""
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "tests", "cpp", "mock_opencv"),
+                           os.path.join(ROOT, "tests", "cpp", "test_adaptor_opencv.cpp"), "-o", BIN_CV, "-L", CSRC, "-lorbfe",
+                           "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_reference_signature_branch_type_checks(built):
+    _build_cv()  # the static_asserts in the source pin the return types of include/ORBextractor.h:62
+    assert "gfx950" in subprocess.check_output([BIN_CV]).decode()
+
+
+@pytest.mark.gpu
+def test_hostmem_overload_equals_view_overload(built, tmp_path):
+    from orbfe import synth
+    _build_cv()
+    W, H = 752, 480
+    (tmp_path / "g.raw").write_bytes(synth.frame(W, H, 11).tobytes())
+    out = subprocess.check_output([BIN_CV, str(W), str(H), str(tmp_path / "g.raw")]).decode()
+    assert "hostmem overload ok" in out
+
+
 def test_adaptor_compiles_and_links(built):
     _build()
     out = subprocess.check_output([BIN]).decode()
