@@ -260,6 +260,16 @@ int orbfe_match_bow(orbfe_handle *h, int n_groups, const int *kf_off, const int 
                     const uint8_t *f_desc, const float *f_angle, float nn_ratio,
                     int check_orientation, int *match_out, int *n_matches);
 
+/* the same for a frame of a two-camera rig (F->Nleft != -1, src/ORBmatcher.cc:205-233,263-286): frame features
+ * >= n_left belong to the right camera and keep their own best / second best; the right best is accepted whenever the
+ * LEFT best passes TH_LOW and its own distance does too (the reference's ratio test there reads "|| true").
+ * n_left == -1 is orbfe_match_bow. */
+int orbfe_match_bow_rig(orbfe_handle *h, int n_groups, const int *kf_off, const int *kf_idx,
+                    const int *f_off, const int *f_idx, int n_kf, const uint8_t *kf_desc,
+                    const float *kf_angle, const uint8_t *kf_has_mp, int n_f,
+                    const uint8_t *f_desc, const float *f_angle, int n_left, float nn_ratio,
+                    int check_orientation, int *match_out, int *n_matches);
+
 /* replaces ORBmatcher::SearchForInitialization(F1, F2, windowSize, nnRatio, checkOrientation)
  * (src/ORBmatcher.cc:329-439; caller src/Tracking.cc:605-607), mono.  HOST pointers.  Frame 1
  * contributes keypoints + descriptors; frame 2 additionally its grid (GetFeaturesInArea runs on

@@ -201,10 +201,11 @@ static void compute_three_maxima(const int *histoSize, int L, int *ind1, int *in
     }
 }
 
-int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx,
-                      int nKF, const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfHasMP,
-                      int nF, const uint8_t *fDesc, const float *fAngle, float nnRatio,
-                      int checkOrientation, int *matchOut)
+/* nLeft = F->Nleft: -1 for one camera, else frame features >= nLeft belong to the right camera (:205-233, :263-286) */
+int orc_search_by_bow_rig(int G, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx,
+                          int nKF, const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfHasMP,
+                          int nF, const uint8_t *fDesc, const float *fAngle, int nLeft, float nnRatio,
+                          int checkOrientation, int *matchOut)
 {
     (void)nKF;
     int nmatches = 0;
@@ -223,16 +224,27 @@ int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff
             if (!kfHasMP[realIdxKF]) continue;                 /* :172-176 */
             const uint8_t *dKF = kfDesc + (size_t)realIdxKF * 32;
             int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
             for (int iF = fOff[g]; iF < fOff[g + 1]; iF++) {
                 const int realIdxF = fIdx[iF];
-                if (matchOut[realIdxF] >= 0) continue;         /* :188-189 */
+                if (matchOut[realIdxF] >= 0) continue;         /* :188-189 / :206-207 */
                 const int dist = orc_hamming(dKF, fDesc + (size_t)realIdxF * 32);
-                if (dist < bestDist1) {
-                    bestDist2 = bestDist1;
-                    bestDist1 = dist;
-                    bestIdxF = realIdxF;
-                } else if (dist < bestDist2) {
-                    bestDist2 = dist;
+                if (nLeft == -1 || realIdxF < nLeft) {         /* :185-203 / :213-220 */
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = realIdxF;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                } else {                                       /* :222-229 */
+                    if (dist < bestDist1R) {
+                        bestDist2R = bestDist1R;
+                        bestDist1R = dist;
+                        bestIdxFR = realIdxF;
+                    } else if (dist < bestDist2R) {
+                        bestDist2R = dist;
+                    }
                 }
             }
             if (bestDist1 <= TH_LOW) {                          /* :237 */
@@ -247,7 +259,18 @@ int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff
                     }
                     nmatches++;
                 }
-                /* :263-286 right-image branch never fires in mono (bestDist1R stays 256) */
+                if (bestDist1R <= TH_LOW) {                     /* :263-286: the ratio test there is "|| true" */
+                    (void)bestDist2R;
+                    matchOut[bestIdxFR] = realIdxKF;
+                    if (checkOrientation) {
+                        float rot = kfAngle[realIdxKF] - fAngle[bestIdxFR];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin][rotN[bin]++] = bestIdxFR;
+                    }
+                    nmatches++;
+                }
             }
         }
     }
@@ -264,6 +287,15 @@ int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff
     }
     for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
     return nmatches;
+}
+
+int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx,
+                      int nKF, const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfHasMP,
+                      int nF, const uint8_t *fDesc, const float *fAngle, float nnRatio,
+                      int checkOrientation, int *matchOut)
+{
+    return orc_search_by_bow_rig(G, kfOff, kfIdx, fOff, fIdx, nKF, kfDesc, kfAngle, kfHasMP, nF, fDesc, fAngle, -1, nnRatio,
+                                 checkOrientation, matchOut);
 }
 
 /* ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:329-439 (caller src/Tracking.cc:605-607).

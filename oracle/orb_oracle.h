@@ -116,6 +116,10 @@ int orc_search_by_projection(const orc_frame_view *F, int M, const orc_map_point
  * group g holds KF feature indices kfIdx[kfOff[g]..kfOff[g+1]) and frame feature indices
  * fIdx[fOff[g]..fOff[g+1]).  kfHasMP[i] != 0 iff KF feature i has a non-bad map point.
  * matchOut[j] = KF feature index whose map point is assigned to frame feature j, or -1. */
+int orc_search_by_bow_rig(int G, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx,
+                          int nKF, const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfHasMP,
+                          int nF, const uint8_t *fDesc, const float *fAngle, int nLeft, float nnRatio,
+                          int checkOrientation, int *matchOut);
 int orc_search_by_bow(int G, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx,
                       int nKF, const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfHasMP,
                       int nF, const uint8_t *fDesc, const float *fAngle, float nnRatio,

@@ -23,6 +23,7 @@ struct BowArgs {
     const uint8_t *kfDesc, *fDesc, *kfHasMP;
     const float *kfAngle, *fAngle;
     int nF;
+    int nLeft;       // F->Nleft: frame features >= nLeft belong to the right camera (-1: one camera)
     float nnRatio;
     int checkOrientation;
     int* matchOut;   // [nF], -1 initialised
@@ -46,33 +47,60 @@ __global__ __launch_bounds__(256) void bow_match_kernel(BowArgs A)
             const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.kfDesc + (size_t)realIdxKF * 32);
             d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
         }
-        unsigned long long k1 = kKeyNone, k2 = kKeyNone;
+        // two camera sides (F->Nleft != -1, :205-233): separate best / second best for the left and the right features
+        const int nLeft = A.nLeft < 0 ? 0x7fffffff : A.nLeft;
+        unsigned long long k1 = kKeyNone, k2 = kKeyNone, r1 = kKeyNone, r2 = kKeyNone;
         for (int iF = f0 + lane; iF < f1; iF += 64) {
             const int realIdxF = A.fIdx[iF];
             if (A.matchOut[realIdxF] >= 0) continue;
             const int dist = hamming256(reinterpret_cast<const uint2*>(A.fDesc + (size_t)realIdxF * 32), d4);
             if (dist >= 256) continue;
             const unsigned long long key = ((unsigned long long)dist << 32) | (unsigned)(iF - f0);
-            if (key < k1) { k2 = k1; k1 = key; }
-            else if (key < k2) k2 = key;
+            if (realIdxF < nLeft) {
+                if (key < k1) { k2 = k1; k1 = key; }
+                else if (key < k2) k2 = key;
+            } else {
+                if (key < r1) { r2 = r1; r1 = key; }
+                else if (key < r2) r2 = key;
+            }
         }
         wave_top2(k1, k2);
-        if (k1 == kKeyNone) continue;
+        if (A.nLeft >= 0) wave_top2(r1, r2);  // wave-uniform
+        if (k1 == kKeyNone) continue;  // bestDist1 == 256 > TH_LOW: neither side is looked at (:237)
         const int bestDist1 = (int)(k1 >> 32);
         const int bestDist2 = k2 == kKeyNone ? 256 : (int)(k2 >> 32);
-        if (bestDist1 <= ORBFE_TH_LOW && (float)bestDist1 < A.nnRatio * (float)bestDist2) {  // :237-239
-            const int bestIdxF = A.fIdx[f0 + (int)(k1 & 0xffffffffu)];
-            if (lane == 0) {
-                A.matchOut[bestIdxF] = realIdxKF;
-                if (A.checkOrientation) {
-                    float rot = A.kfAngle[realIdxKF] - A.fAngle[bestIdxF];
-                    if (rot < 0.0) rot = rot + 360.0f;
-                    int bin = (int)roundf(rot * factor);
-                    if (bin == ORBFE_HISTO_LENGTH) bin = 0;
-                    A.binOf[bestIdxF] = bin;
+        if (bestDist1 <= ORBFE_TH_LOW) {  // :237
+            bool wrote = false;
+            if ((float)bestDist1 < A.nnRatio * (float)bestDist2) {  // :239
+                const int bestIdxF = A.fIdx[f0 + (int)(k1 & 0xffffffffu)];
+                if (lane == 0) {
+                    A.matchOut[bestIdxF] = realIdxKF;
+                    if (A.checkOrientation) {
+                        float rot = A.kfAngle[realIdxKF] - A.fAngle[bestIdxF];
+                        if (rot < 0.0) rot = rot + 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+                        A.binOf[bestIdxF] = bin;
+                    }
                 }
+                wrote = true;
             }
-            __threadfence_block();  // later iterations of this wave read matchOut
+            // right camera (:263-286): accepted whenever its best distance passes TH_LOW (the ratio test is "|| true")
+            if (r1 != kKeyNone && (int)(r1 >> 32) <= ORBFE_TH_LOW) {
+                const int bestIdxFR = A.fIdx[f0 + (int)(r1 & 0xffffffffu)];
+                if (lane == 0) {
+                    A.matchOut[bestIdxFR] = realIdxKF;
+                    if (A.checkOrientation) {
+                        float rot = A.kfAngle[realIdxKF] - A.fAngle[bestIdxFR];
+                        if (rot < 0.0) rot = rot + 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+                        A.binOf[bestIdxFR] = bin;
+                    }
+                }
+                wrote = true;
+            }
+            if (wrote) __threadfence_block();  // later iterations of this wave read matchOut
         }
     }
 }
@@ -129,7 +157,7 @@ __global__ __launch_bounds__(256) void bow_finalize_kernel(BowArgs A)
 
 int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const int* kfIdx, const int* fOff,
                   const int* fIdx, int nKF, const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfHasMP, int nF,
-                  const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation, int* matchOut,
+                  const uint8_t* fDesc, const float* fAngle, int nLeft, float nnRatio, int checkOrientation, int* matchOut,
                   int* nMatches, std::string& err)
 {
     for (int i = 0; i < nF; i++) matchOut[i] = -1;
@@ -185,6 +213,7 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
     A.kfAngle = reinterpret_cast<const float*>(dp + oKfAng);
     A.fAngle = reinterpret_cast<const float*>(dp + oFAng);
     A.nF = nF;
+    A.nLeft = nLeft;
     A.nnRatio = nnRatio;
     A.checkOrientation = checkOrientation;
     A.matchOut = reinterpret_cast<int*>(dp + oMatch);

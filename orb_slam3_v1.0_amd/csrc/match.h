@@ -35,7 +35,7 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
 
 int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const int* kfIdx, const int* fOff,
                   const int* fIdx, int nKF, const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfHasMP,
-                  int nF, const uint8_t* fDesc, const float* fAngle, float nnRatio, int checkOrientation,
+                  int nF, const uint8_t* fDesc, const float* fAngle, int nLeft, float nnRatio, int checkOrientation,
                   int* matchOut, int* nMatches, std::string& err);
 
 // the search part of ORBmatcher::Fuse (kernels_match_kf.hip)

@@ -1545,12 +1545,12 @@ int orbfe_bow_transform(orbfe_handle* h, orbfe_vocab* v, const uint8_t* desc, in
     return rc;
 }
 
-int orbfe_match_bow(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx, const int* f_off, const int* f_idx,
-                    int n_kf, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_has_mp, int n_f,
-                    const uint8_t* f_desc, const float* f_angle, float nn_ratio, int check_orientation, int* match_out,
-                    int* n_matches)
+int orbfe_match_bow_rig(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx, const int* f_off, const int* f_idx,
+                        int n_kf, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_has_mp, int n_f,
+                        const uint8_t* f_desc, const float* f_angle, int n_left, float nn_ratio, int check_orientation,
+                        int* match_out, int* n_matches)
 {
-    if (!h || !match_out || !n_matches || G < 0 || n_kf < 0 || n_f < 0) return ORBFE_ERR_INVALID_ARG;
+    if (!h || !match_out || !n_matches || G < 0 || n_kf < 0 || n_f < 0 || n_left < -1 || n_left > n_f) return ORBFE_ERR_INVALID_ARG;
     if (G > 0 && (!kf_off || !kf_idx || !f_off || !f_idx || !kf_desc || !f_desc || !kf_has_mp)) return ORBFE_ERR_INVALID_ARG;
     if (check_orientation && G > 0 && (!kf_angle || !f_angle)) return ORBFE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1559,9 +1559,18 @@ int orbfe_match_bow(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx
     MatchScope scope_(h, h->stream);
     if (scope_.rc != ORBFE_OK) return scope_.rc;
     int rc = match_bow_run(h->match, h->stream, G, kf_off, kf_idx, f_off, f_idx, n_kf, kf_desc, kf_angle, kf_has_mp, n_f,
-                           f_desc, f_angle, nn_ratio, check_orientation, match_out, n_matches, err);
+                           f_desc, f_angle, n_left, nn_ratio, check_orientation, match_out, n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
+}
+
+int orbfe_match_bow(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx, const int* f_off, const int* f_idx,
+                    int n_kf, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_has_mp, int n_f,
+                    const uint8_t* f_desc, const float* f_angle, float nn_ratio, int check_orientation, int* match_out,
+                    int* n_matches)
+{
+    return orbfe_match_bow_rig(h, G, kf_off, kf_idx, f_off, f_idx, n_kf, kf_desc, kf_angle, kf_has_mp, n_f, f_desc, f_angle, -1,
+                               nn_ratio, check_orientation, match_out, n_matches);
 }
 
 }  // extern "C"

@@ -77,7 +77,7 @@ SYMBOLS = [
     "orbfe_get_level_info", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
     "orbfe_extract_batch_device", "orbfe_get_pyramid_level", "orbfe_debug_get_candidates",
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
-    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
+    "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_bow_rig", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
     "orbfe_prep_create", "orbfe_prep_destroy", "orbfe_prepare_image", "orbfe_prepare_image_device", "orbfe_prepare_and_extract",
     "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
     "orbfe_get_device_status", "orbfe_stream_create", "orbfe_stream_destroy", "orbfe_stream_submit", "orbfe_stream_collect",
@@ -146,6 +146,7 @@ def lib():
     L.orbfe_match_projection_batch_device.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp,
                                                       cf, ci, cf, cf, vp, vp, vp]
     L.orbfe_match_bow.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp, vp]
+    L.orbfe_match_bow_rig.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, cf, ci, vp, vp]
     L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
@@ -534,7 +535,7 @@ class ORBmatcher:
         return n.value, out[:fv1.n].copy()
 
     def SearchByBoW(self, kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAngle, nnRatio,
-                    checkOrientation=True):
+                    checkOrientation=True, nLeft=-1):
         a32 = lambda v: np.ascontiguousarray(v, np.int32)
         kfOff, kfIdx, fOff, fIdx = a32(kfOff), a32(kfIdx), a32(fOff), a32(fIdx)
         kfDesc = np.ascontiguousarray(kfDesc, np.uint8)
@@ -544,10 +545,10 @@ class ORBmatcher:
         kfHasMP = np.ascontiguousarray(kfHasMP, np.uint8)
         out = np.full(max(1, len(fDesc)), -1, np.int32)
         n = C.c_int()
-        self.e._chk(self.L.orbfe_match_bow(self.e.h, len(kfOff) - 1, _p(kfOff), _p(kfIdx), _p(fOff), _p(fIdx),
-                                           len(kfDesc), _p(kfDesc), _p(kfAngle), _p(kfHasMP), len(fDesc), _p(fDesc),
-                                           _p(fAngle), nnRatio, int(checkOrientation), _p(out), C.byref(n)),
-                    "orbfe_match_bow")
+        self.e._chk(self.L.orbfe_match_bow_rig(self.e.h, len(kfOff) - 1, _p(kfOff), _p(kfIdx), _p(fOff), _p(fIdx),
+                                               len(kfDesc), _p(kfDesc), _p(kfAngle), _p(kfHasMP), len(fDesc), _p(fDesc),
+                                               _p(fAngle), int(nLeft), nnRatio, int(checkOrientation), _p(out), C.byref(n)),
+                    "orbfe_match_bow_rig")
         return n.value, out[:len(fDesc)].copy()
 
 

@@ -87,6 +87,7 @@ def lib():
         L.orc_hamming.argtypes = [vp, vp]
         L.orc_search_by_projection.argtypes = [vp, ci, vp, vp, vp, cf, ci, cf, cf, vp]
         L.orc_search_by_bow.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp]
+        L.orc_search_by_bow_rig.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, cf, ci, vp]
         L.orc_assign_grid.argtypes = [vp, vp]
         L.orc_search_for_initialization.argtypes = [vp, vp, ci, cf, ci, vp]
         L.orc_vocab_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, vp]
@@ -270,7 +271,7 @@ def assign_grid(fv):
     return out[:fv.n].copy()
 
 
-def search_by_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAngle, nnRatio, checkOrientation=True):
+def search_by_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAngle, nnRatio, checkOrientation=True, nLeft=-1):
     kfOff = np.ascontiguousarray(kfOff, np.int32)
     kfIdx = np.ascontiguousarray(kfIdx, np.int32)
     fOff = np.ascontiguousarray(fOff, np.int32)
@@ -281,9 +282,9 @@ def search_by_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAngle, kfHasMP, fDesc, fAn
     fAngle = np.ascontiguousarray(fAngle, np.float32)
     kfHasMP = np.ascontiguousarray(kfHasMP, np.uint8)
     out = np.zeros(max(1, len(fDesc)), np.int32)
-    n = lib().orc_search_by_bow(len(kfOff) - 1, _p(kfOff), _p(kfIdx), _p(fOff), _p(fIdx), len(kfDesc),
-                                _p(kfDesc), _p(kfAngle), _p(kfHasMP), len(fDesc), _p(fDesc), _p(fAngle),
-                                nnRatio, int(checkOrientation), _p(out))
+    n = lib().orc_search_by_bow_rig(len(kfOff) - 1, _p(kfOff), _p(kfIdx), _p(fOff), _p(fIdx), len(kfDesc),
+                                    _p(kfDesc), _p(kfAngle), _p(kfHasMP), len(fDesc), _p(fDesc), _p(fAngle),
+                                    int(nLeft), nnRatio, int(checkOrientation), _p(out))
     return n, out[:len(fDesc)].copy()
 
 

@@ -119,6 +119,26 @@ def test_search_by_bow_exact(built, orient, nodes, seed):
     assert n_ref > 20
 
 
+@pytest.mark.parametrize("orient,nodes,seed,left_frac", [(True, 120, 7, 0.5), (False, 60, 8, 0.75), (True, 5, 9, 0.25)])
+def test_search_by_bow_rig_exact(built, orient, nodes, seed, left_frac):
+    """two-camera frame (F->Nleft != -1), src/ORBmatcher.cc:205-233, 263-286"""
+    import orbfe
+    W, H = 752, 480
+    args = (1000, 40000, 1.2, 8, 20, 7, W, H)
+    e = O.Extractor(*args)
+    frames = list(synth.stream(W, H, 2, index0=13))
+    kpk, dk, _ = e.extract(frames[0])
+    kpf, df, _ = e.extract(frames[1])
+    kfOff, kfIdx, fOff, fIdx, has = S.bow_scenario(kpk, dk, kpf, df, nodes, seed)
+    nLeft = int(len(df) * left_frac)
+    n_ref, out_ref = O.search_by_bow(kfOff, kfIdx, fOff, fIdx, dk, kpk["angle"], has, df, kpf["angle"], 0.75, orient, nLeft=nLeft)
+    ex = orbfe.ORBextractor(*args, device=0, max_batch=1)
+    n, out = orbfe.ORBmatcher(ex).SearchByBoW(kfOff, kfIdx, fOff, fIdx, dk, kpk["angle"], has, df, kpf["angle"], 0.75, orient,
+                                             nLeft=nLeft)
+    assert n == n_ref and np.array_equal(out, out_ref)
+    assert n_ref > 10
+
+
 def test_descriptor_distance_host(built):
     import orbfe
     rng = np.random.default_rng(5)

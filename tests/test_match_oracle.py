@@ -118,7 +118,7 @@ def test_grid_wrap_quirk():
     assert cells[2] == -1  # row 48 -> outside the linear range
 
 
-def py_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAng, has, fDesc, fAng, nn, orient):
+def py_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAng, has, fDesc, fAng, nn, orient, nLeft=-1):
     nF = len(fDesc)
     out = [-1] * nF
     hist = [[] for _ in range(30)]
@@ -128,23 +128,35 @@ def py_bow(kfOff, kfIdx, fOff, fIdx, kfDesc, kfAng, has, fDesc, fAng, nn, orient
             if not has[ik]:
                 continue
             b1, b2, bi = 256, 256, -1
+            r1, ri = 256, -1   # right camera of a rig (src/ORBmatcher.cc:222-229)
             for jf in fIdx[fOff[g]:fOff[g + 1]]:
                 if out[jf] >= 0:
                     continue
                 d = int(np.unpackbits(kfDesc[ik] ^ fDesc[jf]).sum())
-                if d < b1:
-                    b2, b1, bi = b1, d, jf
-                elif d < b2:
-                    b2 = d
-            if b1 <= 30 and f32(b1) < f32(f32(nn) * f32(b2)):
-                out[bi] = int(ik)
+                if nLeft == -1 or jf < nLeft:
+                    if d < b1:
+                        b2, b1, bi = b1, d, jf
+                    elif d < b2:
+                        b2 = d
+                elif d < r1:
+                    r1, ri = d, jf
+
+            def accept(idx):
+                out[idx] = int(ik)
                 if orient:
-                    rot = f32(kfAng[ik] - fAng[bi])
+                    rot = f32(kfAng[ik] - fAng[idx])
                     if rot < 0:
                         rot = f32(rot + f32(360.0))
                     b = py_round(float(f32(rot * f32(f32(1.0) / f32(30)))))
-                    hist[0 if b == 30 else b].append(bi)
-                nm += 1
+                    hist[0 if b == 30 else b].append(idx)
+
+            if b1 <= 30:
+                if f32(b1) < f32(f32(nn) * f32(b2)):
+                    accept(bi)
+                    nm += 1
+                if r1 <= 30:   # :263-286, ratio test "|| true"
+                    accept(ri)
+                    nm += 1
     if orient:
         m1 = m2 = m3 = 0
         i1 = i2 = i3 = -1
@@ -181,3 +193,20 @@ def test_bow_oracle_equals_python(orient, nodes, seed):
     n2, out2 = py_bow(kfOff, kfIdx, fOff, fIdx, dk, kpk["angle"], has, df, kpf["angle"], 0.75, orient)
     assert n == n2 and list(out) == out2
     assert n == sum(1 for v in out if v >= 0)
+
+
+@pytest.mark.parametrize("orient,nodes,seed,left_frac", [(True, 40, 4, 0.5), (False, 25, 5, 0.7), (True, 8, 6, 0.3)])
+def test_bow_rig_oracle_equals_python(orient, nodes, seed, left_frac):
+    """F->Nleft != -1 (src/ORBmatcher.cc:205-233, 263-286): frame features >= Nleft are the right camera's."""
+    W, H = 320, 240
+    e = O.Extractor(300, 20000, 1.2, 4, 20, 7, W, H)
+    frames = list(synth.stream(W, H, 2, index0=9))
+    kpk, dk, _ = e.extract(frames[0])
+    kpf, df, _ = e.extract(frames[1])
+    kfOff, kfIdx, fOff, fIdx, has = S.bow_scenario(kpk, dk, kpf, df, nodes, seed)
+    nLeft = int(len(df) * left_frac)
+    n, out = O.search_by_bow(kfOff, kfIdx, fOff, fIdx, dk, kpk["angle"], has, df, kpf["angle"], 0.75, orient, nLeft=nLeft)
+    n2, out2 = py_bow(kfOff, kfIdx, fOff, fIdx, dk, kpk["angle"], has, df, kpf["angle"], 0.75, orient, nLeft)
+    assert n == n2 and list(out) == out2
+    n1, out1 = O.search_by_bow(kfOff, kfIdx, fOff, fIdx, dk, kpk["angle"], has, df, kpf["angle"], 0.75, orient)
+    assert list(out1) != out2  # the rig branch changes the result on this scenario
