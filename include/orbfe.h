@@ -331,11 +331,26 @@ typedef struct orbfe_tri_params {
     int only_stereo;        /* bOnlyStereo */
     int coarse;             /* bCoarse */
     int check_orientation;  /* checkOrientation */
+    /* ---- camera models (zero-initialised == one pinhole camera per key frame, the fields above suffice) ---- */
+    int camera_model1;      /* ORBFE_CAMERA_* of pKF1->mpCamera: KANNALA_BRANDT8 selects KannalaBrandt8::epipolarConstrain
+                             * (src/CameraModels/KannalaBrandt8.cpp:216-220,306-370: triangulate the pair, both depths positive,
+                             * both reprojection errors inside 5.991 sigma^2) instead of the F12 line test */
+    int camera_model2;      /* ORBFE_CAMERA_* of pKF2->mpCamera (unproject / project of the second view) */
+    float cam1[8], cam2[8]; /* mvParameters of the two cameras: fx fy cx cy k1 k2 k3 k4 */
+    float kb_precision;     /* KannalaBrandt8::precision (Newton stop of unproject; the reference's default is 1e-6) */
+    float r12[9], t12[3];   /* T12 = T1w * Tw2 (:466-468; in this fork also when the key frames carry a second camera:
+                             * bRight1 / bRight2 are constants, :520,:549): rotation row-major, translation */
+    float level_sigma2_1[ORBFE_MAX_LEVELS]; /* pKF1->mvLevelSigma2 (sigmaLevel of the first view; unc is 1.0, :603) */
+    int kf1_has_camera2;    /* pKF1->mpCamera2 is set: the epipole gate (:551) is skipped */
 } orbfe_tri_params;
 
 /* replaces ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse,
  * checkOrientation) (src/ORBmatcher.cc:441-676; caller src/LocalMapping.cc:488), one pinhole camera per key
- * frame.  The merge-walk over the two FeatureVectors (:489-617) is handed over as CSR groups in ascending
+ * frame, or KannalaBrandt8 cameras (camera_model1 / camera_model2 of the parameter block: SPEC DECISION S10 -- the
+ * reference triangulates with an Eigen JacobiSVD in binary32, which is not reproducible bit for bit; here the null vector
+ * of the 4x4 system comes from a fixed cyclic-Jacobi sequence on A^T A in binary64, so the verdicts agree with the
+ * reference except for pairs whose depth or reprojection error sits within rounding distance of a threshold).
+ * The merge-walk over the two FeatureVectors (:489-617) is handed over as CSR groups in ascending
  * NodeId order (as for orbfe_match_bow).  has_mp* [i] != 0 iff GetMapPoint(i) is set; stereo* [i] != 0 iff
  * mvuRight[i] >= 0 (NULL == monocular); scale_factors2 = pKF2->mvScaleFactors (n_levels2 floats).
  * matches12_out[i1] (n1 ints) = index in key frame 2 or -1, i.e. vMatchedPairs = {(i1, matches12_out[i1])} in
@@ -358,6 +373,17 @@ int orbfe_fuse_search(orbfe_handle *h, const orbfe_frame_view *KF, const float *
                       const float *u_right, const orbfe_frustum *frustum, float th, int M,
                       const orbfe_world_point *points, const uint8_t *mp_desc, int *best_idx_out,
                       int *best_dist_out);
+
+/* the same with bRight = true (src/ORBmatcher.cc:684-688,:820; callers src/LocalMapping.cc:824,854 when the key frame
+ * has a second camera): frustum carries pKF->GetRightPose() / GetRightTranslationInverse() / mpCamera2; KF_left
+ * describes the LEFT features (KF_left->n == pKF->NLeft -- they fill mGrid, and the level and chi-square gates read them,
+ * as in the reference) while KF_left->desc is all of pKF->mDescriptors: NLeft + n_right rows.  The compared descriptor
+ * row and best_idx_out are idx + NLeft (:820).  Where the reference would read a row beyond the matrix (idx >= n_right)
+ * the candidate is skipped. */
+int orbfe_fuse_search_right(orbfe_handle *h, const orbfe_frame_view *KF_left, int n_right, const float *inv_level_sigma2,
+                            const float *u_right, const orbfe_frustum *frustum, float th, int M,
+                            const orbfe_world_point *points, const uint8_t *mp_desc, int *best_idx_out,
+                            int *best_dist_out);
 
 /* replaces the search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:864-975;
  * no caller in this fork -- the loop-closing thread is gone -- but part of the class, include/ORBmatcher.h:69): the

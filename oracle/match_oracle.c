@@ -543,8 +543,11 @@ void orc_is_in_frustum(const orc_frustum *F, int n, const orc_world_point *pts, 
  * ------------------------------------------------------------------------------------------ */
 static void fuse_search_body(const orc_frame_view *KF, const float *invLevelSigma2, const float *uRight,
                              const orc_frustum *F, float th, int M, const orc_world_point *pts, const uint8_t *mpDesc,
-                             int chi2Gate, int *bestIdxOut, int *bestDistOut)
+                             int chi2Gate, int nRight, int *bestIdxOut, int *bestDistOut)
 {
+    /* nRight >= 0 is bRight (:684-688, :820): KF describes the LEFT features (KF->n == pKF->NLeft, they fill mGrid and the
+     * gates read them), KF->desc is all of mDescriptors (NLeft + nRight rows), the compared row and the returned index
+     * are idx + NLeft.  A row beyond the matrix is skipped (the reference would read out of bounds there). */
     cell_t *g = build_grid(KF);
     int *vIndices = (int *)malloc(sizeof(int) * (size_t)(KF->n > 0 ? KF->n : 1));
     for (int i = 0; i < M; i++) {
@@ -594,10 +597,15 @@ static void fuse_search_body(const orc_frame_view *KF, const float *invLevelSigm
                 const float e2 = ex * ex + ey * ey;
                 if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
             }
-            const int dist = orc_hamming(mpDesc + (size_t)i * 32, KF->desc + (size_t)idx * 32);
+            int row = idx;
+            if (nRight >= 0) {
+                if (idx >= nRight) continue;
+                row = idx + KF->n; /* :820 */
+            }
+            const int dist = orc_hamming(mpDesc + (size_t)i * 32, KF->desc + (size_t)row * 32);
             if (dist < bestDist) {
                 bestDist = dist;
-                bestIdx = idx;
+                bestIdx = row;
             }
         }
         bestIdxOut[i] = bestIdx;
@@ -611,7 +619,16 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
                      float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
                      int *bestDistOut)
 {
-    fuse_search_body(KF, invLevelSigma2, uRight, F, th, M, pts, mpDesc, 1, bestIdxOut, bestDistOut);
+    fuse_search_body(KF, invLevelSigma2, uRight, F, th, M, pts, mpDesc, 1, -1, bestIdxOut, bestDistOut);
+}
+
+/* ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = true): F carries GetRightPose / GetRightTranslationInverse / mpCamera2 */
+void orc_fuse_search_right(const orc_frame_view *KFleft, int nRight, const float *invLevelSigma2, const float *uRight,
+                           const orc_frustum *F, float th, int M, const orc_world_point *pts, const uint8_t *mpDesc,
+                           int *bestIdxOut, int *bestDistOut)
+{
+    fuse_search_body(KFleft, invLevelSigma2, uRight, F, th, M, pts, mpDesc, 1, nRight < 0 ? 0 : nRight, bestIdxOut,
+                     bestDistOut);
 }
 
 /* The search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:864-975):
@@ -622,7 +639,7 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
 void orc_fuse_search_sim3(const orc_frame_view *KF, const orc_frustum *F, float th, int M, const orc_world_point *pts,
                           const uint8_t *mpDesc, int *bestIdxOut, int *bestDistOut)
 {
-    fuse_search_body(KF, NULL, NULL, F, th, M, pts, mpDesc, 0, bestIdxOut, bestDistOut);
+    fuse_search_body(KF, NULL, NULL, F, th, M, pts, mpDesc, 0, -1, bestIdxOut, bestDistOut);
 }
 
 /* PredictScale (src/MapPoint.cc:580-612), SPEC DECISION S8 */
@@ -817,6 +834,145 @@ int orc_search_by_projection_kf(const orc_frame_view *F, const orc_frustum *Fr, 
  * The per-pair float arithmetic follows SPEC DECISION S8 (left to right, no contraction).
  * matches12Out[i1] = index in key frame 2 or -1; returns nmatches.
  * ------------------------------------------------------------------------------------------ */
+/* ---- KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-220) = TriangulateMatches (:306-370)
+ * returning a depth above 0.0001.  SPEC DECISION S10: binary32 one operation at a time as the reference's Eigen / cv
+ * expressions read, EXCEPT the null vector of the 4x4 system A (Triangulate, :385-396), which the reference takes from
+ * Eigen::JacobiSVD<Matrix4f>(A, ComputeFullV) -- an iteration whose rounding is not reproducible outside Eigen.  The spec
+ * takes the eigenvector of the smallest eigenvalue of A^T A, formed in binary64, by eight cyclic Jacobi sweeps in the pair
+ * order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3).  tan(theta) of unproject is sin / cos of the S5 sequences.  PARITY UNPINNED
+ * against Eigen: tests/test_triangulation.py measures the agreement of the verdicts with a float64 SVD restatement. */
+void orc_kb8_unproject(const float cam[8], int model, float precision, float u, float v, float *rx, float *ry)
+{
+    const float pwx = (u - cam[2]) / cam[0];
+    const float pwy = (v - cam[3]) / cam[1];
+    *rx = pwx;
+    *ry = pwy;
+    if (model == 0) return; /* Pinhole::unproject, src/CameraModels/Pinhole.cpp:57-60 */
+    /* KannalaBrandt8::unproject, :115-142 */
+    float scale = 1.0f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    const float kHalfPi = 0x1.921fb6p+0f;
+    theta_d = fminf(fmaxf(-kHalfPi, theta_d), kHalfPi);
+    if (theta_d > 1e-8f) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2,
+                        theta8 = theta4 * theta4;
+            const float k0t2 = cam[4] * theta2, k1t4 = cam[5] * theta4, k2t6 = cam[6] * theta6, k3t8 = cam[7] * theta8;
+            const float num = theta * ((((1.0f + k0t2) + k1t4) + k2t6) + k3t8) - theta_d;
+            const float den = (((1.0f + 3.0f * k0t2) + 5.0f * k1t4) + 7.0f * k2t6) + 9.0f * k3t8;
+            const float fix = num / den;
+            theta = theta - fix;
+            if (fabsf(fix) < precision) break;
+        }
+        float c, sn;
+        orc_cos_sin_deg(theta * 0x1.ca5dc2p+5f, &c, &sn);
+        scale = (sn / c) / theta_d;
+    }
+    *rx = pwx * scale;
+    *ry = pwy * scale;
+}
+
+static void sym4_min_eigenvector(double M[4][4], double vOut[4])
+{
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 8; sweep++)
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                const double apq = M[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double sn = t * c;
+                for (int k = 0; k < 4; k++) {
+                    const double mkp = M[k][p], mkq = M[k][q];
+                    M[k][p] = c * mkp - sn * mkq;
+                    M[k][q] = sn * mkp + c * mkq;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double mpk = M[p][k], mqk = M[q][k];
+                    M[p][k] = c * mpk - sn * mqk;
+                    M[q][k] = sn * mpk + c * mqk;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    int m = 0;
+    for (int i = 1; i < 4; i++)
+        if (M[i][i] < M[m][m]) m = i;
+    for (int k = 0; k < 4; k++) vOut[k] = V[k][m];
+}
+
+static void project_cam(const float cam[8], int model, float x, float y, float z, float *u, float *v)
+{
+    orc_frustum F;
+    memset(&F, 0, sizeof F);
+    F.cameraModel = model;
+    F.fx = cam[0], F.fy = cam[1], F.cx = cam[2], F.cy = cam[3];
+    F.k1 = cam[4], F.k2 = cam[5], F.k3 = cam[6], F.k4 = cam[7];
+    camera_project(&F, x, y, z, u, v);
+}
+
+int orc_kb8_epipolar_constrain(const orc_tri_cameras *C, float u1, float v1, float u2, float v2, float sigmaLevel,
+                               float unc, float xyzOut[3])
+{
+    float r1x, r1y, r2x, r2y;
+    orc_kb8_unproject(C->cam1, C->model1, C->precision, u1, v1, &r1x, &r1y);
+    orc_kb8_unproject(C->cam2, C->model2, C->precision, u2, v2, &r2x, &r2y);
+    const float *R12 = C->R12, *t12 = C->t12;
+    /* :313-319 */
+    const float r21x = (R12[0] * r2x + R12[1] * r2y) + R12[2];
+    const float r21y = (R12[3] * r2x + R12[4] * r2y) + R12[5];
+    const float r21z = (R12[6] * r2x + R12[7] * r2y) + R12[8];
+    const float dot = (r1x * r21x + r1y * r21y) + r21z;
+    const float n1 = sqrtf((r1x * r1x + r1y * r1y) + 1.0f);
+    const float n2 = sqrtf((r21x * r21x + r21y * r21y) + r21z * r21z);
+    const float cosParallax = dot / (n1 * n2);
+    if ((double)cosParallax > 0.9998) return 0;
+    /* :333-336 */
+    float R21[9], tc[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R21[3 * i + j] = R12[3 * j + i];
+    for (int i = 0; i < 3; i++) tc[i] = -((R21[3 * i] * t12[0] + R21[3 * i + 1] * t12[1]) + R21[3 * i + 2] * t12[2]);
+    /* Triangulate, :385-396, Tcw1 = [I | 0] */
+    float A[4][4];
+    A[0][0] = -1.0f, A[0][1] = 0.0f, A[0][2] = r1x, A[0][3] = 0.0f;
+    A[1][0] = 0.0f, A[1][1] = -1.0f, A[1][2] = r1y, A[1][3] = 0.0f;
+    for (int j = 0; j < 3; j++) {
+        A[2][j] = r2x * R21[6 + j] - R21[j];
+        A[3][j] = r2y * R21[6 + j] - R21[3 + j];
+    }
+    A[2][3] = r2x * tc[2] - tc[0];
+    A[3][3] = r2y * tc[2] - tc[1];
+    double M[4][4], vv[4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; k++) acc = acc + (double)A[k][i] * (double)A[k][j];
+            M[i][j] = acc;
+        }
+    sym4_min_eigenvector(M, vv);
+    const float X = (float)(vv[0] / vv[3]), Y = (float)(vv[1] / vv[3]), Z = (float)(vv[2] / vv[3]);
+    if (xyzOut) xyzOut[0] = X, xyzOut[1] = Y, xyzOut[2] = Z;
+    if (!(Z > 0.0f)) return 0; /* :343-346 */
+    const float z2 = ((R21[6] * X + R21[7] * Y) + R21[8] * Z) + tc[2];
+    if (!(z2 > 0.0f)) return 0; /* :348-351 */
+    float pu, pv;
+    project_cam(C->cam1, C->model1, X, Y, Z, &pu, &pv); /* :354-361 */
+    const float e1x = pu - u1, e1y = pv - v1;
+    if ((double)(e1x * e1x + e1y * e1y) > 5.991 * (double)sigmaLevel) return 0;
+    const float X2 = ((R21[0] * X + R21[1] * Y) + R21[2] * Z) + tc[0];
+    const float Y2 = ((R21[3] * X + R21[4] * Y) + R21[5] * Z) + tc[1];
+    project_cam(C->cam2, C->model2, X2, Y2, z2, &pu, &pv); /* :363-371 */
+    const float e2x = pu - u2, e2y = pv - v2;
+    if ((double)(e2x * e2x + e2y * e2y) > 5.991 * (double)unc) return 0;
+    return Z > 0.0001f; /* :218-219 */
+}
+
 int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const int *off2, const int *idx2v, int n1,
                                  const orc_keypoint *kp1, const uint8_t *desc1, const uint8_t *hasMP1,
                                  const uint8_t *stereo1, int n2, const orc_keypoint *kp2, const uint8_t *desc2,
@@ -824,6 +980,20 @@ int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const
                                  const float *F12, float epx, float epy, int bOnlyStereo, int bCoarse,
                                  int checkOrientation, int *matches12Out)
 {
+    return orc_search_for_triangulation_cam(G, off1, idx1v, off2, idx2v, n1, kp1, desc1, hasMP1, stereo1, n2, kp2, desc2,
+                                            hasMP2, stereo2, scaleFactors2, F12, epx, epy, bOnlyStereo, bCoarse,
+                                            checkOrientation, NULL, matches12Out);
+}
+
+int orc_search_for_triangulation_cam(int G, const int *off1, const int *idx1v, const int *off2, const int *idx2v, int n1,
+                                     const orc_keypoint *kp1, const uint8_t *desc1, const uint8_t *hasMP1,
+                                     const uint8_t *stereo1, int n2, const orc_keypoint *kp2, const uint8_t *desc2,
+                                     const uint8_t *hasMP2, const uint8_t *stereo2, const float *scaleFactors2,
+                                     const float *F12, float epx, float epy, int bOnlyStereo, int bCoarse,
+                                     int checkOrientation, const orc_tri_cameras *cams, int *matches12Out)
+{
+    const int kb8 = cams && cams->model1 == 1;
+    const int noEpipoleGate = cams && cams->kf1HasCamera2;
     (void)n2;
     int nmatches = 0;
     for (int i = 0; i < n1; i++) matches12Out[i] = -1;
@@ -850,7 +1020,7 @@ int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const
                 const int dist = orc_hamming(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
                 if (dist > TH_LOW || dist > bestDist) continue; /* :545: ties replace the earlier one */
                 const orc_keypoint *k2 = &kp2[idx2];
-                if (!bStereo1 && !bStereo2) { /* :551-565 */
+                if (!bStereo1 && !bStereo2 && !noEpipoleGate) { /* :551-565 */
                     const float distex = epx - k2->x, distey = epy - k2->y;
                     const float err = distex * distex + distey * distey;
                     if (err < 100 * scaleFactors2[k2->octave]) continue;
@@ -862,7 +1032,11 @@ int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const
                 const float num = (a * k2->x + b * k2->y) + c;
                 const float den = a * a + b * b;
                 int ok = 0;
-                if (den != 0) {
+                if (kb8) { /* pCamera1 is the KannalaBrandt8 of pKF1: :603 with sigma = mvLevelSigma2[kp1.octave], unc 1 */
+                    if (!bCoarse)
+                        ok = orc_kb8_epipolar_constrain(cams, k1->x, k1->y, k2->x, k2->y, cams->sigma2_1[k1->octave], 1.0f,
+                                                        NULL);
+                } else if (den != 0) {
                     const float dsqr = num * num / den;
                     ok = dsqr < 3.84 * 1.0; /* float against a double constant */
                 }

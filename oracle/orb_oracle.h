@@ -157,6 +157,11 @@ void orc_fuse_search(const orc_frame_view *KF, const float *invLevelSigma2, cons
                      float th, int M, const orc_world_point *pts, const uint8_t *mpDesc, int *bestIdxOut,
                      int *bestDistOut);
 
+/* the same with bRight = true (:684-688, :820) */
+void orc_fuse_search_right(const orc_frame_view *KFleft, int nRight, const float *invLevelSigma2, const float *uRight,
+                           const orc_frustum *F, float th, int M, const orc_world_point *pts, const uint8_t *mpDesc,
+                           int *bestIdxOut, int *bestDistOut);
+
 /* the search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:864-975) */
 void orc_fuse_search_sim3(const orc_frame_view *KF, const orc_frustum *F, float th, int M, const orc_world_point *pts,
                           const uint8_t *mpDesc, int *bestIdxOut, int *bestDistOut);
@@ -186,6 +191,26 @@ int orc_search_for_triangulation(int G, const int *off1, const int *idx1v, const
                                  const uint8_t *hasMP2, const uint8_t *stereo2, const float *scaleFactors2,
                                  const float *F12, float epx, float epy, int bOnlyStereo, int bCoarse,
                                  int checkOrientation, int *matches12Out);
+
+/* the same with the camera models of the two key frames: KannalaBrandt8 for pKF1 selects
+ * KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-220,306-370), SPEC DECISION S10 */
+typedef struct {
+    int model1, model2;     /* 0 pinhole, 1 KannalaBrandt8 */
+    float cam1[8], cam2[8]; /* fx fy cx cy k1 k2 k3 k4 */
+    float precision;        /* KannalaBrandt8::precision */
+    float R12[9], t12[3];   /* T12 = T1w * Tw2 (src/ORBmatcher.cc:466-468) */
+    float sigma2_1[32]; /* pKF1->mvLevelSigma2 (ORC_MAX_LEVELS entries) */
+    int kf1HasCamera2;      /* pKF1->mpCamera2: no epipole gate (:551) */
+} orc_tri_cameras;
+int orc_kb8_epipolar_constrain(const orc_tri_cameras *C, float u1, float v1, float u2, float v2, float sigmaLevel,
+                               float unc, float xyzOut[3]);
+void orc_kb8_unproject(const float cam[8], int model, float precision, float u, float v, float *rx, float *ry);
+int orc_search_for_triangulation_cam(int G, const int *off1, const int *idx1v, const int *off2, const int *idx2v, int n1,
+                                     const orc_keypoint *kp1, const uint8_t *desc1, const uint8_t *hasMP1,
+                                     const uint8_t *stereo1, int n2, const orc_keypoint *kp2, const uint8_t *desc2,
+                                     const uint8_t *hasMP2, const uint8_t *stereo2, const float *scaleFactors2,
+                                     const float *F12, float epx, float epy, int bOnlyStereo, int bCoarse,
+                                     int checkOrientation, const orc_tri_cameras *cams, int *matches12Out);
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:343-416) for a batch of descriptor sets */
 void orc_distinctive_descriptors(int nSets, const int *setOff, const uint8_t *desc, int *bestIdxOut,

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frus
                                                           const uint8_t* __restrict__ mpDesc,
                                                           const float* __restrict__ invLevelSigma2,
                                                           const float* __restrict__ uRight, int chi2Gate,
+                                                          const unsigned long long* __restrict__ rightDesc, int nRight,
                                                           int* __restrict__ bestIdxOut, int* __restrict__ bestDistOut)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -98,13 +99,18 @@ __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frus
                         if ((double)(e2 * invS2) > 5.99) continue;
                     }
                     const unsigned long long* kd = A.descS + (size_t)sl * 4;
+                    if (rightDesc) {  // bRight (:820): the left feature passed the gates, its right twin's row is compared
+                        const int idx = A.order[rq.x];
+                        if (idx >= nRight) continue;
+                        kd = rightDesc + (size_t)idx * 4;
+                    }
                     const int dist = __popcll(kd[0] ^ d0) + __popcll(kd[1] ^ d1) + __popcll(kd[2] ^ d2) + __popcll(kd[3] ^ d3);
                     best = min(best, make_key32(dist, rq.x));
                 }
             }
         }
         if (best != kKey32None) {
-            bestIdx = A.order[best & kRankMask];
+            bestIdx = A.order[best & kRankMask] + (rightDesc ? A.kpStride : 0);
             bestDist = (int)(best >> kRankBits);
         }
     } while (false);
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void reloc_finalize_kernel(int n, const orbfe_
 
 int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, const float* invLevelSigma2,
                     const float* uRight, const orbfe_frustum* F, float th, int M, const orbfe_world_point* pts,
-                    const uint8_t* mpDesc, int chi2Gate, int* bestIdxOut, int* bestDistOut, std::string& err)
+                    const uint8_t* mpDesc, int chi2Gate, int nRight, int* bestIdxOut, int* bestDistOut, std::string& err)
 {
     if (!chi2Gate) {
         invLevelSigma2 = nullptr;
@@ -343,6 +349,7 @@ int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, 
     const size_t oIs2 = in.take((size_t)KF->n_levels * sizeof(float));
     const size_t oUr = in.take((size_t)n * sizeof(float));
     const size_t oN = in.take(sizeof(int));
+    const size_t oRight = in.take((size_t)(nRight > 0 ? nRight : 0) * 32);  // rows NLeft .. of mDescriptors (bRight)
     const size_t inBytes = in.off;
     const size_t oMatch = in.take((size_t)n * sizeof(int));  // the grid kernel clears a match array
     const size_t oBest = in.take((size_t)M * 2 * sizeof(int));
@@ -363,6 +370,7 @@ int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, 
     if (invLevelSigma2) memcpy(hp + oIs2, invLevelSigma2, (size_t)KF->n_levels * sizeof(float));
     if (uRight) memcpy(hp + oUr, uRight, (size_t)n * sizeof(float));
     memcpy(hp + oN, &n, sizeof(int));
+    if (nRight > 0) memcpy(hp + oRight, KF->desc + (size_t)n * 32, (size_t)nRight * 32);
     MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
     A.kp = reinterpret_cast<const orbfe_keypoint*>(dp + oKp);
     A.desc = dp + oDesc;
@@ -374,7 +382,8 @@ int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, 
     hipLaunchKernelGGL(fuse_search_kernel, dim3((M + 255) / 256), dim3(256), 0, s, A, *F, th, M,
                        reinterpret_cast<const orbfe_world_point*>(dp + oPts), dp + oMpDesc,
                        reinterpret_cast<const float*>(dp + oIs2), uRight ? reinterpret_cast<const float*>(dp + oUr) : nullptr,
-                       chi2Gate, dBest, dBest + M);
+                       chi2Gate, nRight >= 0 ? reinterpret_cast<const unsigned long long*>(dp + oRight) : nullptr, nRight, dBest,
+                       dBest + M);
     MCHK(hipGetLastError());
     int* hBest = reinterpret_cast<int*>(hp + inBytes);
     MCHK(hipMemcpyAsync(hBest, dBest, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToHost, s));

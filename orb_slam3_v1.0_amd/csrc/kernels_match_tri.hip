@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "match_common.h"
+#include "device_math.h"
 
 #pragma clang fp contract(off)
 
@@ -36,11 +37,152 @@ struct TriArgs {
     float F12[9];
     float epx, epy;
     int onlyStereo, coarse, checkOrientation;
+    int model1, model2, kf1HasCamera2;
+    float cam1[8], cam2[8], kbPrecision;
+    float R12[9], t12[3];
+    float sigma2_1[kMaxLevels];
     int n1;
     int* match12;                 // [n1]
     int* binOf;                   // [n1]
     int* nMatches;
 };
+
+
+// ---- KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-220 -> TriangulateMatches :306-370) ----
+// SPEC DECISION S10.  binary32, one operation per line, no contraction, except the null vector of the 4x4 system, which the
+// reference takes from an Eigen JacobiSVD (not reproducible): here A^T A in binary64, eight cyclic Jacobi sweeps in the
+// fixed pair order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3), eigenvector of the smallest eigenvalue (lowest index on ties).
+// tan(theta) of unproject is sin / cos of the S5 sequences.  Same sequence as oracle/match_oracle.c kb8_epipolar.
+struct CamP {
+    float fx, fy, cx, cy, k1, k2, k3, k4;
+    int camera_model;
+};
+
+__device__ __forceinline__ CamP cam_of(const float (&c)[8], int model)
+{
+    return CamP{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], model};
+}
+
+__device__ inline void cam_unproject(const CamP& C, float precision, float u, float v, float& rx, float& ry)
+{
+    const float pwx = (u - C.cx) / C.fx;
+    const float pwy = (v - C.cy) / C.fy;
+    rx = pwx;
+    ry = pwy;
+    if (C.camera_model == 0) return;  // Pinhole::unproject (src/CameraModels/Pinhole.cpp:57-60)
+    // KannalaBrandt8::unproject (:115-142): Newton on theta (1 + k1 theta^2 + ...) = theta_d
+    float scale = 1.0f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    const float kHalfPi = 0x1.921fb6p+0f;
+    theta_d = fminf(fmaxf(-kHalfPi, theta_d), kHalfPi);
+    if (theta_d > 1e-8f) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0t2 = C.k1 * theta2, k1t4 = C.k2 * theta4, k2t6 = C.k3 * theta6, k3t8 = C.k4 * theta8;
+            const float num = theta * ((((1.0f + k0t2) + k1t4) + k2t6) + k3t8) - theta_d;
+            const float den = (((1.0f + 3.0f * k0t2) + 5.0f * k1t4) + 7.0f * k2t6) + 9.0f * k3t8;
+            const float fix = num / den;
+            theta = theta - fix;
+            if (fabsf(fix) < precision) break;
+        }
+        float c, sn;
+        cos_sin_deg(theta * 0x1.ca5dc2p+5f, c, sn);  // theta in [0, pi/2] as degrees
+        scale = (sn / c) / theta_d;
+    }
+    rx = pwx * scale;
+    ry = pwy * scale;
+}
+
+// smallest-eigenvalue eigenvector of the symmetric 4x4 matrix M (destroyed)
+__device__ inline void sym4_min_eigenvector(double (&M)[4][4], double (&vOut)[4])
+{
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 8; sweep++) {
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                const double apq = M[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double sn = t * c;
+                for (int k = 0; k < 4; k++) {  // columns p, q of M
+                    const double mkp = M[k][p], mkq = M[k][q];
+                    M[k][p] = c * mkp - sn * mkq;
+                    M[k][q] = sn * mkp + c * mkq;
+                }
+                for (int k = 0; k < 4; k++) {  // rows p, q of M
+                    const double mpk = M[p][k], mqk = M[q][k];
+                    M[p][k] = c * mpk - sn * mqk;
+                    M[q][k] = sn * mpk + c * mqk;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int i = 1; i < 4; i++)
+        if (M[i][i] < M[m][m]) m = i;
+    for (int k = 0; k < 4; k++) vOut[k] = V[k][m];
+}
+
+__device__ inline bool kb8_epipolar(const CamP& C1, const CamP& C2, float precision, float u1, float v1, float u2, float v2,
+                                    const float (&R12)[9], const float (&t12)[3], float sigmaLevel, float unc)
+{
+    float r1x, r1y, r2x, r2y;
+    cam_unproject(C1, precision, u1, v1, r1x, r1y);  // rays (x, y, 1)
+    cam_unproject(C2, precision, u2, v2, r2x, r2y);
+    // parallax (:313-319)
+    const float r21x = (R12[0] * r2x + R12[1] * r2y) + R12[2];
+    const float r21y = (R12[3] * r2x + R12[4] * r2y) + R12[5];
+    const float r21z = (R12[6] * r2x + R12[7] * r2y) + R12[8];
+    const float dot = (r1x * r21x + r1y * r21y) + r21z;
+    const float n1 = sqrtf((r1x * r1x + r1y * r1y) + 1.0f);
+    const float n2 = sqrtf((r21x * r21x + r21y * r21y) + r21z * r21z);
+    const float cosParallax = dot / (n1 * n2);
+    if ((double)cosParallax > 0.9998) return false;
+    // Tcw2 = [R21 | -R21 t12], R21 = R12^T (:333-336)
+    float R21[9], tc[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R21[3 * i + j] = R12[3 * j + i];
+    for (int i = 0; i < 3; i++) tc[i] = -((R21[3 * i] * t12[0] + R21[3 * i + 1] * t12[1]) + R21[3 * i + 2] * t12[2]);
+    // A (:401-405) with Tcw1 = [I | 0]
+    float A[4][4];
+    A[0][0] = -1.0f; A[0][1] = 0.0f; A[0][2] = r1x; A[0][3] = 0.0f;
+    A[1][0] = 0.0f; A[1][1] = -1.0f; A[1][2] = r1y; A[1][3] = 0.0f;
+    for (int j = 0; j < 3; j++) {
+        A[2][j] = r2x * R21[6 + j] - R21[j];
+        A[3][j] = r2y * R21[6 + j] - R21[3 + j];
+    }
+    A[2][3] = r2x * tc[2] - tc[0];
+    A[3][3] = r2y * tc[2] - tc[1];
+    double M[4][4], vv[4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; k++) acc = acc + (double)A[k][i] * (double)A[k][j];
+            M[i][j] = acc;
+        }
+    sym4_min_eigenvector(M, vv);
+    const float X = (float)(vv[0] / vv[3]), Y = (float)(vv[1] / vv[3]), Z = (float)(vv[2] / vv[3]);
+    if (!(Z > 0.0f)) return false;  // :343-346 (NaN fails, as a comparison "<= 0" on NaN would pass in the reference: S10)
+    const float z2 = ((R21[6] * X + R21[7] * Y) + R21[8] * Z) + tc[2];
+    if (!(z2 > 0.0f)) return false;  // :348-351
+    float pu, pv;
+    camera_project(C1, X, Y, Z, pu, pv);  // :354-361
+    const float e1x = pu - u1, e1y = pv - v1;
+    if ((double)(e1x * e1x + e1y * e1y) > 5.991 * (double)sigmaLevel) return false;
+    const float X2 = ((R21[0] * X + R21[1] * Y) + R21[2] * Z) + tc[0];
+    const float Y2 = ((R21[3] * X + R21[4] * Y) + R21[5] * Z) + tc[1];
+    camera_project(C2, X2, Y2, z2, pu, pv);  // :363-371
+    const float e2x = pu - u2, e2y = pv - v2;
+    if ((double)(e2x * e2x + e2y * e2y) > 5.991 * (double)unc) return false;
+    return Z > 0.0001f;  // :218-219
+}
 
 __global__ __launch_bounds__(256) void tri_match_kernel(TriArgs A)
 {
@@ -69,16 +211,22 @@ __global__ __launch_bounds__(256) void tri_match_kernel(TriArgs A)
         const int dist = hamming256(reinterpret_cast<const uint2*>(A.desc2 + (size_t)idx2 * 32), d4);
         if (dist > ORBFE_TH_LOW || dist > bestDist) continue;  // :545
         const orbfe_keypoint k2 = A.kp2[idx2];
-        if (!bStereo1 && !bStereo2) {  // :551-565
+        if (!bStereo1 && !bStereo2 && !A.kf1HasCamera2) {  // :551-565
             const float distex = A.epx - k2.x, distey = A.epy - k2.y;
             const float err = distex * distex + distey * distey;
             if (err < 100 * A.sf2[k2.octave]) continue;
         }
-        const float num = (a * k2.x + b * k2.y) + c;
         bool ok = false;
-        if (den != 0) {
-            const float dsqr = num * num / den;
-            ok = (double)dsqr < 3.84 * 1.0;
+        if (A.model1 == ORBFE_CAMERA_KANNALA_BRANDT8) {  // block-uniform
+            if (!A.coarse)  // (the reference evaluates it either way; its result is only used without bCoarse)
+                ok = kb8_epipolar(cam_of(A.cam1, A.model1), cam_of(A.cam2, A.model2), A.kbPrecision, k1.x, k1.y, k2.x, k2.y, A.R12,
+                                  A.t12, A.sigma2_1[k1.octave], 1.0f);
+        } else {
+            const float num = (a * k2.x + b * k2.y) + c;
+            if (den != 0) {
+                const float dsqr = num * num / den;
+                ok = (double)dsqr < 3.84 * 1.0;
+            }
         }
         if (A.coarse || ok) {
             bestIdx2 = idx2;
@@ -228,6 +376,20 @@ int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* of
     A.onlyStereo = P->only_stereo;
     A.coarse = P->coarse;
     A.checkOrientation = P->check_orientation;
+    A.model1 = P->camera_model1;
+    A.model2 = P->camera_model2;
+    A.kf1HasCamera2 = P->kf1_has_camera2;
+    for (int i = 0; i < 8; i++) {
+        A.cam1[i] = P->cam1[i];
+        A.cam2[i] = P->cam2[i];
+    }
+    A.kbPrecision = P->kb_precision;
+    for (int i = 0; i < 9; i++) A.R12[i] = P->r12[i];
+    for (int i = 0; i < 3; i++) A.t12[i] = P->t12[i];
+    for (int i = 0; i < kMaxLevels; i++) A.sigma2_1[i] = P->level_sigma2_1[i];
+    if (P->camera_model1 == ORBFE_CAMERA_KANNALA_BRANDT8)
+        for (int i = 0; i < n1; i++)
+            if (kp1[i].octave < 0 || kp1[i].octave >= kMaxLevels) return ORBFE_ERR_INVALID_ARG;  // indexes mvLevelSigma2
     A.n1 = n1;
     A.match12 = reinterpret_cast<int*>(dp + oMatch);
     A.binOf = reinterpret_cast<int*>(dp + oBin);

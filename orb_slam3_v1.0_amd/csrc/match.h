@@ -41,7 +41,7 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
 // the search part of ORBmatcher::Fuse (kernels_match_kf.hip)
 int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, const float* invLevelSigma2,
                     const float* uRight, const orbfe_frustum* F, float th, int M, const orbfe_world_point* pts,
-                    const uint8_t* mpDesc, int chi2Gate, int* bestIdxOut, int* bestDistOut, std::string& err);
+                    const uint8_t* mpDesc, int chi2Gate, int nRight, int* bestIdxOut, int* bestDistOut, std::string& err);
 // ORBmatcher::SearchBySim3 and the relocalisation SearchByProjection overload (kernels_match_kf.hip)
 int search_by_sim3_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF1, const orbfe_frame_view* KF2,
                        const orbfe_sim3_view* d12, const orbfe_sim3_view* d21, const orbfe_world_point* mp1,

@@ -1233,8 +1233,29 @@ int orbfe_fuse_search(orbfe_handle* h, const orbfe_frame_view* KF, const float* 
     std::string err;
     MatchScope scope_(h, h->stream);
     if (scope_.rc != ORBFE_OK) return scope_.rc;
-    const int rc = fuse_search_run(h->match, h->stream, KF, inv_level_sigma2, u_right, frustum, th, M, points, mp_desc, 1,
+    const int rc = fuse_search_run(h->match, h->stream, KF, inv_level_sigma2, u_right, frustum, th, M, points, mp_desc, 1, -1,
                                    best_idx_out, best_dist_out, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+int orbfe_fuse_search_right(orbfe_handle* h, const orbfe_frame_view* KF, int n_right, const float* inv_level_sigma2,
+                            const float* u_right, const orbfe_frustum* frustum, float th, int M, const orbfe_world_point* points,
+                            const uint8_t* mp_desc, int* best_idx_out, int* best_dist_out)
+{
+    if (!h || !KF || !inv_level_sigma2 || M < 0 || KF->n < 0 || n_right < 0 ||
+        (KF->n > 0 && (!KF->kp || !KF->desc || !KF->scale_factors)) ||
+        (M > 0 && (!points || !mp_desc || !best_idx_out || !best_dist_out)))
+        return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
+    const int rc = fuse_search_run(h->match, h->stream, KF, inv_level_sigma2, u_right, frustum, th, M, points, mp_desc, 1,
+                                   n_right, best_idx_out, best_dist_out, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
 }
@@ -1256,7 +1277,7 @@ int orbfe_fuse_search_sim3(orbfe_handle* h, const orbfe_frame_view* KF, const or
     std::string err;
     MatchScope scope_(h, h->stream);
     if (scope_.rc != ORBFE_OK) return scope_.rc;
-    const int rc = fuse_search_run(h->match, h->stream, KF, nullptr, nullptr, frustum, th, M, points, mp_desc, 0,
+    const int rc = fuse_search_run(h->match, h->stream, KF, nullptr, nullptr, frustum, th, M, points, mp_desc, 0, -1,
                                    best_idx_out, best_dist_out, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;

@@ -61,7 +61,26 @@ class Sim3View(C.Structure):
 class TriParams(C.Structure):
     """orbfe_tri_params: F12, epipole and the three flags of SearchForTriangulation."""
     _fields_ = [("f12", C.c_float * 9), ("ep_x", C.c_float), ("ep_y", C.c_float), ("only_stereo", C.c_int),
-                ("coarse", C.c_int), ("check_orientation", C.c_int)]
+                ("coarse", C.c_int), ("check_orientation", C.c_int),
+                ("camera_model1", C.c_int), ("camera_model2", C.c_int), ("cam1", C.c_float * 8), ("cam2", C.c_float * 8),
+                ("kb_precision", C.c_float), ("r12", C.c_float * 9), ("t12", C.c_float * 3),
+                ("level_sigma2_1", C.c_float * 32), ("kf1_has_camera2", C.c_int)]
+
+
+def fill_tri_cameras(P, cameras):
+    """copy a cameras dict (see ORBmatcher.SearchForTriangulation) into the tail of an orbfe_tri_params"""
+    P.camera_model1, P.camera_model2 = int(cameras["model1"]), int(cameras["model2"])
+    for i in range(8):
+        P.cam1[i] = float(cameras["cam1"][i])
+        P.cam2[i] = float(cameras["cam2"][i])
+    P.kb_precision = float(cameras.get("precision", 1e-6))
+    for i, v in enumerate(np.asarray(cameras["R12"], np.float32).reshape(-1)):
+        P.r12[i] = float(v)
+    for i, v in enumerate(np.asarray(cameras["t12"], np.float32).reshape(-1)):
+        P.t12[i] = float(v)
+    for i, v in enumerate(np.asarray(cameras["levelSigma2_1"], np.float32).reshape(-1)):
+        P.level_sigma2_1[i] = float(v)
+    P.kf1_has_camera2 = int(cameras.get("kf1HasCamera2", 0))
 
 
 class FrameView(C.Structure):
@@ -79,7 +98,7 @@ SYMBOLS = [
     "orbfe_set_stage_timing", "orbfe_get_stage_ms", "orbfe_stage_name", "orbfe_hamming",
     "orbfe_match_projection", "orbfe_match_projection_batch_device", "orbfe_match_bow", "orbfe_match_bow_rig", "orbfe_match_initialization", "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
     "orbfe_prep_create", "orbfe_prep_destroy", "orbfe_prepare_image", "orbfe_prepare_image_device", "orbfe_prepare_and_extract",
-    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
+    "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_right", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
     "orbfe_get_device_status", "orbfe_stream_create", "orbfe_stream_destroy", "orbfe_stream_submit", "orbfe_stream_collect",
     "orbfe_stream_collect_view", "orbfe_stream_in_flight",
 ]
@@ -151,6 +170,7 @@ def lib():
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
+    L.orbfe_fuse_search_right.argtypes = [vp, C.POINTER(FrameView), ci, vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
     L.orbfe_prep_create.argtypes = [vp, ci, ci, vp, vp, ci, ci, C.POINTER(vp)]
     L.orbfe_prep_destroy.argtypes = [vp]
     L.orbfe_prep_destroy.restype = None
@@ -433,8 +453,11 @@ class ORBmatcher:
         return out[:n], xr[:n]
 
     def SearchForTriangulation(self, off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1, kp2, desc2, hasMP2, stereo2,
-                               scaleFactors2, F12, ep, bOnlyStereo=False, bCoarse=False, checkOrientation=True):
-        """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:441-676): returns (nmatches, vMatches12)."""
+                               scaleFactors2, F12, ep, bOnlyStereo=False, bCoarse=False, checkOrientation=True, cameras=None):
+        """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:441-676): returns (nmatches, vMatches12).
+        cameras (optional) = dict(model1, model2, cam1[8], cam2[8], precision, R12[3x3], t12[3], levelSigma2_1,
+        kf1HasCamera2): the camera models of the two key frames; model1 == CAMERA_KANNALA_BRANDT8 selects
+        KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-220)."""
         a32 = lambda v: np.ascontiguousarray(v, np.int32)
         u8 = lambda v: None if v is None else np.ascontiguousarray(v, np.uint8)
         off1, idx1, off2, idx2 = a32(off1), a32(idx1), a32(off2), a32(idx2)
@@ -447,6 +470,8 @@ class ORBmatcher:
             P.f12[i] = float(v)
         P.ep_x, P.ep_y = float(ep[0]), float(ep[1])
         P.only_stereo, P.coarse, P.check_orientation = int(bOnlyStereo), int(bCoarse), int(checkOrientation)
+        if cameras is not None:
+            fill_tri_cameras(P, cameras)
         out = np.full(max(len(kp1), 1), -1, np.int32)
         n = C.c_int()
         self.e._chk(self.L.orbfe_match_triangulation(self.e.h, len(off1) - 1, _p(off1), _p(idx1), _p(off2), _p(idx2), len(kp1),
@@ -479,6 +504,21 @@ class ORBmatcher:
         bd = np.zeros(max(M, 1), np.int32)
         self.e._chk(self.L.orbfe_fuse_search(self.e.h, C.byref(kf_view), _p(is2), _p(ur), C.byref(frustum), th, M,
                                              _p(points), _p(mpDesc), _p(bi), _p(bd)), "orbfe_fuse_search")
+        return bi[:M], bd[:M]
+
+    def Fuse_search_right(self, kf_left_view, nRight, invLevelSigma2, uRight, frustum, th, points, mpDesc):
+        """Fuse(pKF, vpMapPoints, th, bRight = true) (src/ORBmatcher.cc:684-688,:820): kf_left_view describes the NLeft left
+        features with desc = all NLeft + nRight rows of mDescriptors; frustum = right pose / mpCamera2; returned indices are
+        idx + NLeft."""
+        points = np.ascontiguousarray(points, WP_DTYPE)
+        mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+        is2 = np.ascontiguousarray(invLevelSigma2, np.float32)
+        ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        M = len(points)
+        bi = np.zeros(max(M, 1), np.int32)
+        bd = np.zeros(max(M, 1), np.int32)
+        self.e._chk(self.L.orbfe_fuse_search_right(self.e.h, C.byref(kf_left_view), int(nRight), _p(is2), _p(ur), C.byref(frustum),
+                                                   th, M, _p(points), _p(mpDesc), _p(bi), _p(bd)), "orbfe_fuse_search_right")
         return bi[:M], bd[:M]
 
     def Fuse_search_sim3(self, kf_view, frustum, th, points, mpDesc):

@@ -334,6 +334,23 @@ def fuse_search(kf_view, invLevelSigma2, uRight, frustum, th, points, mpDesc):
     return bi[:M], bd[:M]
 
 
+def fuse_search_right(kf_left_view, nRight, invLevelSigma2, uRight, frustum, th, points, mpDesc):
+    points = np.ascontiguousarray(points, WP_DTYPE)
+    mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+    is2 = np.ascontiguousarray(invLevelSigma2, np.float32)
+    ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+    M = len(points)
+    bi = np.zeros(max(M, 1), np.int32)
+    bd = np.zeros(max(M, 1), np.int32)
+    L = lib()
+    L.orc_fuse_search_right.restype = None
+    L.orc_fuse_search_right.argtypes = [C.POINTER(FrameView), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Frustum), C.c_float, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_fuse_search_right(C.byref(kf_left_view), int(nRight), _p(is2), _p(ur), C.byref(frustum), th, M, _p(points), _p(mpDesc),
+                            _p(bi), _p(bd))
+    return bi[:M], bd[:M]
+
+
 def prepare_image(bgr, map1, map2, dst_w, dst_h, want_undistorted=False):
     """ImageGrabber::ConvertImageToGPU (image_grabber.hpp:96-110), SPEC DECISION S9."""
     bgr = np.ascontiguousarray(bgr, np.uint8)
@@ -383,8 +400,55 @@ def search_by_projection_kf(fv, frustum, points, mpDesc, kfAngle, frameHasMP, th
     return n, out[:fv.n]
 
 
+class TriCameras(C.Structure):
+    """orc_tri_cameras"""
+    _fields_ = [("model1", C.c_int), ("model2", C.c_int), ("cam1", C.c_float * 8), ("cam2", C.c_float * 8),
+                ("precision", C.c_float), ("R12", C.c_float * 9), ("t12", C.c_float * 3), ("sigma2_1", C.c_float * 32),
+                ("kf1HasCamera2", C.c_int)]
+
+
+def tri_cameras(cameras):
+    T = TriCameras()
+    T.model1, T.model2 = int(cameras["model1"]), int(cameras["model2"])
+    for i in range(8):
+        T.cam1[i] = float(cameras["cam1"][i])
+        T.cam2[i] = float(cameras["cam2"][i])
+    T.precision = float(cameras.get("precision", 1e-6))
+    for i, v in enumerate(np.asarray(cameras["R12"], np.float32).reshape(-1)):
+        T.R12[i] = float(v)
+    for i, v in enumerate(np.asarray(cameras["t12"], np.float32).reshape(-1)):
+        T.t12[i] = float(v)
+    for i, v in enumerate(np.asarray(cameras["levelSigma2_1"], np.float32).reshape(-1)):
+        T.sigma2_1[i] = float(v)
+    T.kf1HasCamera2 = int(cameras.get("kf1HasCamera2", 0))
+    return T
+
+
+def kb8_epipolar_constrain(cameras, u1, v1, u2, v2, sigmaLevel, unc=1.0):
+    """(verdict, triangulated point in camera 1) of KannalaBrandt8::epipolarConstrain, SPEC DECISION S10"""
+    L = lib()
+    L.orc_kb8_epipolar_constrain.restype = C.c_int
+    L.orc_kb8_epipolar_constrain.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p]
+    T = tri_cameras(cameras)
+    xyz = np.zeros(3, np.float32)
+    ok = L.orc_kb8_epipolar_constrain(C.addressof(T), float(np.float32(u1)), float(np.float32(v1)), float(np.float32(u2)),
+                                      float(np.float32(v2)), float(np.float32(sigmaLevel)), float(np.float32(unc)), _p(xyz))
+    return bool(ok), xyz
+
+
+def kb8_unproject(cam, model, precision, u, v):
+    L = lib()
+    L.orc_kb8_unproject.restype = None
+    L.orc_kb8_unproject.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    c = np.ascontiguousarray(cam, np.float32)
+    rx, ry = C.c_float(), C.c_float()
+    L.orc_kb8_unproject(_p(c), int(model), float(np.float32(precision)), float(np.float32(u)), float(np.float32(v)),
+                        C.addressof(rx), C.addressof(ry))
+    return rx.value, ry.value
+
+
 def search_for_triangulation(off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1, kp2, desc2, hasMP2, stereo2,
-                             scaleFactors2, F12, ep, bOnlyStereo=False, bCoarse=False, checkOrientation=True):
+                             scaleFactors2, F12, ep, bOnlyStereo=False, bCoarse=False, checkOrientation=True, cameras=None):
     a32 = lambda v: np.ascontiguousarray(v, np.int32)
     u8 = lambda v: None if v is None else np.ascontiguousarray(v, np.uint8)
     off1, idx1, off2, idx2 = a32(off1), a32(idx1), a32(off2), a32(idx2)
@@ -393,6 +457,16 @@ def search_for_triangulation(off1, idx1, off2, idx2, kp1, desc1, hasMP1, stereo1
     sf = np.ascontiguousarray(scaleFactors2, np.float32)
     F = np.ascontiguousarray(np.asarray(F12, np.float32).reshape(-1))
     out = np.full(max(len(kp1), 1), -1, np.int32)
+    if cameras is not None:
+        T = tri_cameras(cameras)
+        L = lib()
+        L.orc_search_for_triangulation_cam.restype = C.c_int
+        L.orc_search_for_triangulation_cam.argtypes = list(L.orc_search_for_triangulation.argtypes[:-1]) + [C.c_void_p, C.c_void_p]
+        n = L.orc_search_for_triangulation_cam(len(off1) - 1, _p(off1), _p(idx1), _p(off2), _p(idx2), len(kp1), _p(kp1),
+                                               _p(desc1), _p(h1), _p(s1), len(kp2), _p(kp2), _p(desc2), _p(h2), _p(s2), _p(sf),
+                                               _p(F), float(np.float32(ep[0])), float(np.float32(ep[1])), int(bOnlyStereo),
+                                               int(bCoarse), int(checkOrientation), C.addressof(T), _p(out))
+        return n, out[:len(kp1)].copy()
     n = lib().orc_search_for_triangulation(len(off1) - 1, _p(off1), _p(idx1), _p(off2), _p(idx2), len(kp1), _p(kp1),
                                            _p(desc1), _p(h1), _p(s1), len(kp2), _p(kp2), _p(desc2), _p(h2), _p(s2), _p(sf),
                                            _p(F), float(np.float32(ep[0])), float(np.float32(ep[1])), int(bOnlyStereo),

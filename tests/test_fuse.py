@@ -42,7 +42,7 @@ def scenario(kp, desc, sf, v, M, seed, stereo):
     return pts, mpd, u_right, inv_sigma2
 
 
-def py_fuse_one(kp, desc, sf, inv_s2, u_right, v, th, p, d, grid=(64, 48), chi2=True):
+def py_fuse_one(kp, desc, sf, inv_s2, u_right, v, th, p, d, grid=(64, 48), chi2=True, n_right=None):
     """Plain restatement of :722-826 for one map point on top of the pinned isInFrustum arithmetic; candidates are
     visited in GetFeaturesInArea order (cell x, cell y, index) with the strict '<' of :819."""
     f32 = np.float32
@@ -85,9 +85,14 @@ def py_fuse_one(kp, desc, sf, inv_s2, u_right, v, th, p, d, grid=(64, 48), chi2=
         e2 = f32(f32(ex * ex) + f32(ey * ey))
         if chi2 and float(f32(e2 * inv_s2[k["octave"]])) > 5.99:  # the Sim3 overload (:864-975) has no gate
             continue
-        dist = int(np.unpackbits(desc[i] ^ d).sum())
+        row = i
+        if n_right is not None:   # bRight (:820): desc holds NLeft + n_right rows, the right twin's row is compared
+            if i >= n_right:
+                continue
+            row = i + len(kp)
+        dist = int(np.unpackbits(desc[row] ^ d).sum())
         if dist < best:
-            best, best_i = dist, i
+            best, best_i = dist, row
     return best_i, best
 
 
@@ -129,3 +134,61 @@ def test_gpu_fuse_search_matches_oracle(built, M, th, stereo, seed, kb8):
     # empty inputs
     bi0, bd0 = m.Fuse_search(fv, inv_s2, u_right, Fp, th, pts[:0].view(orbfe.WP_DTYPE), mpd[:0])
     assert len(bi0) == 0
+
+
+def right_scenario(kp, desc, seed, n_right):
+    """mDescriptors of a two-camera key frame: NLeft left rows followed by n_right right rows (right twin i of left
+    feature i: a few flipped bits, some unrelated)"""
+    rng = np.random.default_rng(seed)
+    right = np.stack([S.flip_bits(desc[i], int(rng.integers(0, 50)), rng) for i in range(n_right)])
+    bad = rng.random(n_right) < 0.2
+    right[bad] = rng.integers(0, 256, (int(bad.sum()), 32), dtype=np.uint8)
+    return np.ascontiguousarray(np.concatenate([desc, right]))
+
+
+def test_oracle_fuse_right_matches_restatement(built):
+    from orbfe import synth
+    eo = O.Extractor(*ARGS)
+    kp, desc, _ = eo.extract(synth.frame(W, H, 9))
+    n_right = len(kp) - 150   # fewer right than left features: rows beyond the matrix are skipped
+    all_desc = right_scenario(kp, desc, 3, n_right)
+    Fo = O.Frustum()
+    v = FS.fill_frustum(Fo, ON, seed=27)
+    pts, mpd, _, inv_s2 = scenario(kp, desc, eo.scaleFactors, v, 160, 8, False)
+    fv = O.make_frame_view(kp, all_desc, 64, 48, 0.0, 0.0, float(W), float(H), eo.scaleFactors)
+    bi, bd = O.fuse_search_right(fv, n_right, inv_s2, None, Fo, 3.0, pts, mpd)
+    assert (bd <= 30).sum() > 15 and bi[bi >= 0].min() >= len(kp) and bi.max() < len(kp) + n_right
+    for i in range(len(pts)):
+        assert py_fuse_one(kp, all_desc, eo.scaleFactors, inv_s2, None, v, 3.0, pts[i], mpd[i], n_right=n_right) == (int(bi[i]), int(bd[i])), i
+    # no right features at all
+    bi0, bd0 = O.fuse_search_right(fv, 0, inv_s2, None, Fo, 3.0, pts, mpd)
+    assert (bi0 == -1).all() and (bd0 == 256).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,th,stereo,seed,kb8,short", [(1500, 3.0, False, 1, False, 0), (1200, 4.0, True, 2, True, 150), (600, 8.0, False, 3, True, 700)])
+def test_gpu_fuse_search_right_matches_oracle(built, M, th, stereo, seed, kb8, short):
+    import orbfe
+    from orbfe import synth
+    eo = O.Extractor(*ARGS)
+    kp, desc, _ = eo.extract(synth.frame(W, H, 16 + seed))
+    n_right = len(kp) - short
+    all_desc = right_scenario(kp, desc, seed, n_right)
+    ex = orbfe.ORBextractor(*ARGS)
+    m = orbfe.ORBmatcher(ex)
+    Fo, Fp = O.Frustum(), orbfe.Frustum()
+    v = FS.fill_frustum(Fo, ON, seed=40 + seed, kb8=kb8)
+    FS.fill_frustum(Fp, PN, seed=40 + seed, kb8=kb8)
+    pts, mpd, u_right, inv_s2 = scenario(kp, desc, eo.scaleFactors, v, M, seed, stereo)
+    fvo = O.make_frame_view(kp, all_desc, 64, 48, 0.0, 0.0, float(W), float(H), eo.scaleFactors)
+    bi_r, bd_r = O.fuse_search_right(fvo, n_right, inv_s2, u_right, Fo, th, pts, mpd)
+    fv = orbfe.make_frame_view(kp, all_desc, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    bi, bd = m.Fuse_search_right(fv, n_right, inv_s2, u_right, Fp, th, pts.view(orbfe.WP_DTYPE), mpd)
+    assert np.array_equal(bd, bd_r) and np.array_equal(bi, bi_r)
+    assert (bi_r >= len(kp)).sum() > 20 and bi_r.max() < len(kp) + n_right
+    # the left call on the same view is unchanged by the extra rows
+    bi_l, bd_l = m.Fuse_search(fv, inv_s2, u_right, Fp, th, pts.view(orbfe.WP_DTYPE), mpd)
+    bi_lr, bd_lr = O.fuse_search(fvo, inv_s2, u_right, Fo, th, pts, mpd)
+    assert np.array_equal(bi_l, bi_lr) and np.array_equal(bd_l, bd_lr)
+    bi0, bd0 = m.Fuse_search_right(fv, 0, inv_s2, u_right, Fp, th, pts.view(orbfe.WP_DTYPE), mpd)
+    assert (bi0 == -1).all() and (bd0 == 256).all()

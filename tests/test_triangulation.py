@@ -166,3 +166,275 @@ def test_gpu_triangulation_matches_oracle(built, seed, consistent, stereo, only_
     n0, out0 = m.SearchForTriangulation([0], [], [0], [], kp.view(orbfe.KP_DTYPE), desc, h1, s1, kp2.view(orbfe.KP_DTYPE), d2,
                                         h2, s2, ex.mvScaleFactor, F12, ep)
     assert n0 == 0 and (out0 == -1).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# KannalaBrandt8 key frames: the epipolar test is KannalaBrandt8::epipolarConstrain (triangulate + reproject), S10
+# ---------------------------------------------------------------------------------------------------------------------
+KB_W, KB_H = 512, 512
+KB_ARGS = (1000, 40000, 1.2, 8, 20, 7, KB_W, KB_H)
+KB_CAM = np.array([190.978, 190.973, 254.932, 256.897, 0.00348, 0.000715, -0.00205, 0.000203])  # a TUM-VI like lens
+PIN_CAM = np.array([458.654, 457.296, 255.2, 250.4, 0, 0, 0, 0])
+
+
+def rot(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def project64(cam, model, P):
+    if model == 0:
+        return np.array([cam[0] * P[0] / P[2] + cam[2], cam[1] * P[1] / P[2] + cam[3]])
+    th = np.arctan2(np.hypot(P[0], P[1]), P[2])
+    psi = np.arctan2(P[1], P[0])
+    r = th + cam[4] * th**3 + cam[5] * th**5 + cam[6] * th**7 + cam[7] * th**9
+    return np.array([cam[0] * r * np.cos(psi) + cam[2], cam[1] * r * np.sin(psi) + cam[3]])
+
+
+def unproject64(cam, model, u, v):
+    x, y = (u - cam[2]) / cam[0], (v - cam[3]) / cam[1]
+    if model == 0:
+        return np.array([x, y, 1.0])
+    td = min(max(np.hypot(x, y), -np.pi / 2), np.pi / 2)
+    s = 1.0
+    if td > 1e-8:
+        th = td
+        for _ in range(50):
+            t2 = th * th
+            num = th * (1 + cam[4] * t2 + cam[5] * t2**2 + cam[6] * t2**3 + cam[7] * t2**4) - td
+            den = 1 + 3 * cam[4] * t2 + 5 * cam[5] * t2**2 + 7 * cam[6] * t2**3 + 9 * cam[7] * t2**4
+            th -= num / den
+        s = np.tan(th) / td
+    return np.array([x * s, y * s, 1.0])
+
+
+def kb8_epipolar_f64(cams, u1, v1, u2, v2, sigma, unc):
+    """KannalaBrandt8::TriangulateMatches (:306-370) in binary64 with numpy's SVD: (verdict, smallest relative distance
+    of any tested quantity to its threshold, triangulated point)."""
+    R12, t12 = np.asarray(cams["R12"], np.float64).reshape(3, 3), np.asarray(cams["t12"], np.float64)
+    r1 = unproject64(cams["cam1"], cams["model1"], u1, v1)
+    r2 = unproject64(cams["cam2"], cams["model2"], u2, v2)
+    r21 = R12 @ r2
+    cosp = r1 @ r21 / (np.linalg.norm(r1) * np.linalg.norm(r21))
+    margin = [abs(cosp - 0.9998) / 0.9998]
+    if cosp > 0.9998:
+        return False, margin[0], None
+    R21 = R12.T
+    T2 = np.hstack([R21, (-R21 @ t12)[:, None]])
+    T1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    A = np.stack([r1[0] * T1[2] - T1[0], r1[1] * T1[2] - T1[1], r2[0] * T2[2] - T2[0], r2[1] * T2[2] - T2[1]])
+    _, sv, Vt = np.linalg.svd(A)
+    X = Vt[3, :3] / Vt[3, 3]
+    z1 = X[2]
+    X2 = R21 @ X - R21 @ t12
+    margin += [abs(z1) / (abs(z1) + 1), abs(X2[2]) / (abs(X2[2]) + 1)]
+    if z1 <= 0 or X2[2] <= 0:
+        return False, min(margin), X
+    e1 = project64(cams["cam1"], cams["model1"], X) - np.array([u1, v1])
+    e2 = project64(cams["cam2"], cams["model2"], X2) - np.array([u2, v2])
+    margin += [abs(e1 @ e1 - 5.991 * sigma) / (5.991 * sigma), abs(e2 @ e2 - 5.991 * unc) / (5.991 * unc)]
+    ok = (e1 @ e1 <= 5.991 * sigma) and (e2 @ e2 <= 5.991 * unc) and z1 > 0.0001
+    return bool(ok), min(margin), X
+
+
+def kb_cameras(model2=1, has_cam2=False, seed=0):
+    rng = np.random.default_rng(1000 + seed)
+    R12 = rot(*rng.normal(0, 0.04, 3))
+    t12 = np.array([0.18, 0.02, -0.03]) + rng.normal(0, 0.02, 3)
+    sigma2 = np.array([1.2 ** (2 * l) for l in range(8)], np.float32)
+    return dict(model1=1, model2=model2, cam1=KB_CAM, cam2=KB_CAM if model2 == 1 else PIN_CAM, precision=1e-6,
+                R12=R12.astype(f32), t12=t12.astype(f32), levelSigma2_1=sigma2, kf1HasCamera2=int(has_cam2))
+
+
+def kb_pairs(cams, n, seed, noise=1.0):
+    """image point pairs of 3-D points seen by both cameras (+ pixel noise): (u1, v1, u2, v2, octave)"""
+    rng = np.random.default_rng(seed)
+    R12, t12 = np.asarray(cams["R12"], np.float64).reshape(3, 3), np.asarray(cams["t12"], np.float64)
+    out = []
+    while len(out) < n:
+        u1, v1 = rng.uniform(20, KB_W - 20), rng.uniform(20, KB_H - 20)
+        if np.hypot(u1 - KB_CAM[2], v1 - KB_CAM[3]) > 240:
+            continue
+        ray = unproject64(cams["cam1"], 1, u1, v1)
+        X = ray * rng.uniform(0.4, 12.0)
+        X2 = R12.T @ (X - t12)
+        if X2[2] < 0.05:
+            continue
+        p2 = project64(cams["cam2"], cams["model2"], X2) + rng.normal(0, noise, 2)
+        if not (5 < p2[0] < KB_W - 5 and 5 < p2[1] < KB_H - 5):
+            continue
+        out.append((f32(u1), f32(v1), f32(p2[0]), f32(p2[1]), int(rng.integers(0, 8))))
+    return out
+
+
+def test_kb8_unproject_inverts_project(built):
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(400):
+        u, v = rng.uniform(0, KB_W), rng.uniform(0, KB_H)
+        if np.hypot(u - KB_CAM[2], v - KB_CAM[3]) > 240:   # theta_d <= 1.26: beyond pi/2 the reference clamps (lens corners)
+            continue
+        rx, ry = O.kb8_unproject(KB_CAM, 1, 1e-6, u, v)
+        ref = unproject64(KB_CAM, 1, float(f32(u)), float(f32(v)))
+        worst = max(worst, abs(rx - ref[0]) / (1 + abs(ref[0])), abs(ry - ref[1]) / (1 + abs(ref[1])))
+        back = project64(KB_CAM, 1, np.array([rx, ry, 1.0]))
+        assert abs(back[0] - u) < 2e-2 and abs(back[1] - v) < 2e-2
+    assert worst < 2e-5  # binary32 Newton + polynomial sin/cos against binary64 + libm
+    # pinhole camera: the normalised coordinates themselves
+    rx, ry = O.kb8_unproject(PIN_CAM, 0, 1e-6, 300.0, 200.0)
+    assert rx == f32(f32(300.0 - f32(PIN_CAM[2])) / f32(PIN_CAM[0])) and ry == f32(f32(200.0 - f32(PIN_CAM[3])) / f32(PIN_CAM[1]))
+
+
+@pytest.mark.parametrize("model2", [1, 0])
+def test_kb8_epipolar_spec_against_float64_svd(built, model2):
+    """S10 is parity-unpinned against Eigen's JacobiSVD; this measures it against a binary64 SVD restatement of the same
+    function: the verdicts agree except within a small relative distance of a threshold, the triangulated points agree to
+    binary32 accuracy scaled by the conditioning (loose bound below)."""
+    cams = kb_cameras(model2)
+    pairs = kb_pairs(cams, 1500, 11 + model2, noise=1.2)
+    agree, accepted, near = 0, 0, 0
+    for (u1, v1, u2, v2, octv) in pairs:
+        sig = float(cams["levelSigma2_1"][octv])
+        ok, X = O.kb8_epipolar_constrain(cams, u1, v1, u2, v2, sig, 1.0)
+        ok64, margin, X64 = kb8_epipolar_f64(cams, float(u1), float(v1), float(u2), float(v2), sig, 1.0)
+        accepted += ok64
+        if ok == ok64:
+            agree += 1
+        else:
+            near += 1
+            assert margin < 2e-3, (u1, v1, u2, v2, margin)   # only threshold-grazing pairs may flip
+        if ok and ok64:
+            assert np.linalg.norm(X - X64) <= 2e-2 * np.linalg.norm(X64), (X, X64)
+    assert accepted > 300 and len(pairs) - accepted > 150   # both verdicts are exercised
+    assert agree >= 0.995 * len(pairs), (agree, near)
+
+
+def kb_scenario(kp, desc, cams, seed, stereo):
+    """key frame 2 sees the 3-D points behind key frame 1's features (random depths) through its own camera"""
+    rng = np.random.default_rng(seed)
+    R12, t12 = np.asarray(cams["R12"], np.float64).reshape(3, 3), np.asarray(cams["t12"], np.float64)
+    src, uv2 = [], []
+    for i in range(len(kp)):
+        if rng.random() < 0.15:
+            continue
+        X = unproject64(cams["cam1"], 1, float(kp["x"][i]), float(kp["y"][i])) * rng.uniform(0.5, 10.0)
+        X2 = R12.T @ (X - t12)
+        if X2[2] < 0.05:
+            continue
+        p2 = project64(cams["cam2"], cams["model2"], X2) + rng.normal(0, 0.9 * 1.2 ** kp["octave"][i], 2)
+        if 16 < p2[0] < KB_W - 16 and 16 < p2[1] < KB_H - 16:
+            src.append(i)
+            uv2.append(p2)
+    src = np.array(src)
+    kp2 = kp[src].copy()
+    kp2["x"], kp2["y"] = np.array(uv2)[:, 0].astype(f32), np.array(uv2)[:, 1].astype(f32)
+    kp2["angle"] = (kp2["angle"] + rng.normal(0, 3, len(src))).astype(f32) % 360
+    d2 = np.stack([S.flip_bits(desc[s], int(rng.integers(0, 34)), rng) for s in src])
+    perm = rng.permutation(len(kp2))
+    kp2, d2 = kp2[perm], d2[perm]
+    node1 = (kp["y"] // 64).astype(int) * 8 + kp["octave"]
+    node2 = node1[src][perm]
+    node2 = np.where(rng.random(len(node2)) < 0.05, rng.integers(0, node1.max() + 1, len(node2)), node2)
+    off1, idx1, off2, idx2 = [0], [], [0], []
+    for g in sorted(set(node1) & set(node2)):
+        idx1 += list(np.flatnonzero(node1 == g))
+        idx2 += list(rng.permutation(np.flatnonzero(node2 == g)))
+        off1.append(len(idx1))
+        off2.append(len(idx2))
+    has1 = rng.random(len(kp)) < 0.2
+    has2 = rng.random(len(kp2)) < 0.2
+    s1 = (rng.random(len(kp)) < 0.3) if stereo else None
+    s2 = (rng.random(len(kp2)) < 0.3) if stereo else None
+    # the epipole (C2 in camera 1, :470-477) sits inside the image so that the gate removes features when it is active
+    ep = project64(cams["cam1"], 1, t12 + np.array([0, 0, 0.35]))
+    return off1, idx1, off2, idx2, kp2, d2, has1, has2, s1, s2, np.zeros((3, 3), f32), (f32(ep[0]), f32(ep[1]))
+
+
+def py_tri_kb8(cams, off1, idx1, off2, idx2, kp1, d1, h1, s1, kp2, d2, h2, s2, sf2, ep, only_stereo, coarse):
+    """the loop of :489-617 around the oracle's S10 predicate, no orientation check"""
+    out = np.full(len(kp1), -1, np.int64)
+    for g in range(len(off1) - 1):
+        for a1 in idx1[off1[g]:off1[g + 1]]:
+            st1 = bool(s1 is not None and s1[a1])
+            if h1[a1] or (only_stereo and not st1):
+                continue
+            best, best2 = TH_LOW, -1
+            for a2 in idx2[off2[g]:off2[g + 1]]:
+                st2 = bool(s2 is not None and s2[a2])
+                if h2[a2] or (only_stereo and not st2):
+                    continue
+                dist = int(np.unpackbits(d1[a1] ^ d2[a2]).sum())
+                if dist > TH_LOW or dist > best:
+                    continue
+                k1, k2 = kp1[a1], kp2[a2]
+                if not st1 and not st2 and not cams["kf1HasCamera2"]:
+                    ex, ey = f32(f32(ep[0]) - k2["x"]), f32(f32(ep[1]) - k2["y"])
+                    if f32(f32(ex * ex) + f32(ey * ey)) < f32(f32(100) * sf2[k2["octave"]]):
+                        continue
+                ok = coarse or O.kb8_epipolar_constrain(cams, k1["x"], k1["y"], k2["x"], k2["y"],
+                                                        cams["levelSigma2_1"][k1["octave"]], 1.0)[0]
+                if ok:
+                    best, best2 = dist, a2
+            out[a1] = best2
+    return int((out >= 0).sum()), out
+
+
+KB_CASES = [(1, 1, False, False, False, True), (2, 0, False, True, False, False), (3, 1, True, True, True, True),
+            (4, 1, False, False, False, True)]
+
+
+def _kb_frame(seed):
+    from orbfe import synth
+    eo = O.Extractor(*KB_ARGS)
+    kp, desc, _ = eo.extract(synth.frame(KB_W, KB_H, 60 + seed))
+    return eo, kp, desc
+
+
+@pytest.mark.parametrize("seed,model2,has_cam2,stereo,only_stereo,coarse", KB_CASES + [(5, 1, True, False, False, False)])
+def test_oracle_kb8_triangulation_matches_restatement(built, seed, model2, has_cam2, stereo, only_stereo, coarse):
+    eo, kp, desc = _kb_frame(seed)
+    kp, desc = kp[:350], desc[:350]
+    cams = kb_cameras(model2, has_cam2, seed)
+    off1, idx1, off2, idx2, kp2, d2, h1, h2, s1, s2, F12, ep = kb_scenario(kp, desc, cams, seed, stereo)
+    n, out = O.search_for_triangulation(off1, idx1, off2, idx2, kp, desc, h1, s1, kp2, d2, h2, s2, eo.scaleFactors, F12, ep,
+                                        only_stereo, coarse, False, cameras=cams)
+    n_py, out_py = py_tri_kb8(cams, off1, idx1, off2, idx2, kp, desc, h1, s1, kp2, d2, h2, s2, eo.scaleFactors, ep, only_stereo,
+                              coarse)
+    assert n == n_py and np.array_equal(out, out_py)
+    assert n > 10
+
+
+def test_oracle_kb8_epipole_gate_depends_on_camera2(built):
+    """pKF1->mpCamera2 set: the epipole gate (:551) is off, so features next to the epipole can match"""
+    eo, kp, desc = _kb_frame(7)
+    res = []
+    for has_cam2 in (False, True):
+        cams = kb_cameras(1, has_cam2, 7)
+        off1, idx1, off2, idx2, kp2, d2, h1, h2, s1, s2, F12, ep = kb_scenario(kp, desc, cams, 7, False)
+        kp2 = kp2.copy()
+        kp2["x"][:], kp2["y"][:] = ep[0] + 3.0, ep[1] - 2.0   # every candidate sits on the epipole
+        res.append(O.search_for_triangulation(off1, idx1, off2, idx2, kp, desc, h1, None, kp2, d2, h2, None, eo.scaleFactors,
+                                              F12, ep, False, True, False, cameras=cams)[0])
+    assert res[0] == 0 and res[1] > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,model2,has_cam2,stereo,only_stereo,coarse", KB_CASES)
+def test_gpu_kb8_triangulation_matches_oracle(built, seed, model2, has_cam2, stereo, only_stereo, coarse):
+    import orbfe
+    eo, kp, desc = _kb_frame(seed)
+    ex = orbfe.ORBextractor(*KB_ARGS)
+    m = orbfe.ORBmatcher(ex)
+    cams = kb_cameras(model2, has_cam2, seed)
+    off1, idx1, off2, idx2, kp2, d2, h1, h2, s1, s2, F12, ep = kb_scenario(kp, desc, cams, seed, stereo)
+    for check in (False, True):
+        n_ref, out_ref = O.search_for_triangulation(off1, idx1, off2, idx2, kp, desc, h1, s1, kp2, d2, h2, s2, eo.scaleFactors,
+                                                    F12, ep, only_stereo, coarse, check, cameras=cams)
+        n, out = m.SearchForTriangulation(off1, idx1, off2, idx2, kp.view(orbfe.KP_DTYPE), desc, h1, s1,
+                                          kp2.view(orbfe.KP_DTYPE), d2, h2, s2, ex.mvScaleFactor, F12, ep, only_stereo, coarse,
+                                          check, cameras=cams)
+        assert n == n_ref and np.array_equal(out, out_ref), (check, n, n_ref)
+    assert n_ref > 10
