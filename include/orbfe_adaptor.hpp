@@ -305,9 +305,10 @@ public:
         for (int i = 0; i < nF; i++) fAngle[i] = (*F->mvKeysUn)[i].angle;
         std::vector<int> match(nF > 0 ? nF : 1);
         int nmatches = 0;
-        orbfe_detail::check(orbfe_match_bow(h, (int)kfOff.size() - 1, kfOff.data(), kfIdx.data(), fOff.data(), fIdx.data(), nKF,
-                                            kfDesc(pKF), kfAngle.data(), hasMP.data(), nF, frameDesc(F), fAngle.data(), nnRatio,
-                                            checkOrientation, match.data(), &nmatches), h, "orbfe_match_bow");
+        // F->Nleft != -1 (two-camera rig): features >= Nleft keep their own best / second best (:205-233,263-286)
+        orbfe_detail::check(orbfe_match_bow_rig(h, (int)kfOff.size() - 1, kfOff.data(), kfIdx.data(), fOff.data(), fIdx.data(), nKF,
+                                                kfDesc(pKF), kfAngle.data(), hasMP.data(), nF, frameDesc(F), fAngle.data(), F->Nleft,
+                                                nnRatio, checkOrientation, match.data(), &nmatches), h, "orbfe_match_bow_rig");
         for (int j = 0; j < nF; j++)
             if (match[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[match[j]];  // :241
         return nmatches;
@@ -319,7 +320,9 @@ public:
 struct KeyFrameMatcher {
     // src/ORBmatcher.cc:441-676.  `KF` needs: N, mvKeysUn, mFeatVec (std::map<NodeId, vector<unsigned>>), GetMapPoint(i),
     // mvuRight, mvScaleFactors; descriptors through descOf(pKF) (N x 32 bytes).  F12 / ep are computed by the caller
-    // with the reference's own expressions (Pinhole.cpp:106-109, ORBmatcher.cc:451-454) and passed in `prm`.
+    // with the reference's own expressions (Pinhole.cpp:106-109, ORBmatcher.cc:451-454) and passed in `prm`; for
+    // KannalaBrandt8 key frames the caller also fills prm's camera block (T12 of :466-468, both parameter vectors,
+    // mvLevelSigma2 of pKF1, whether pKF1->mpCamera2 is set) and the test becomes KannalaBrandt8::epipolarConstrain.
     template <class KeyFramePtr, class DescOf>
     static int SearchForTriangulation(orbfe_handle* h, KeyFramePtr pKF1, KeyFramePtr pKF2, const orbfe_tri_params& prm,
                                       std::vector<std::pair<size_t, size_t>>& vMatchedPairs, DescOf descOf)
@@ -365,13 +368,17 @@ struct KeyFrameMatcher {
         return nmatches;
     }
 
-    // src/ORBmatcher.cc:678-851 (bRight == false).  The search result of every map point is computed first; the
+    // src/ORBmatcher.cc:678-851.  bRight (the key frame of a two-camera rig, src/LocalMapping.cc:824,854): `frustum`
+    // carries GetRightPose / GetRightTranslationInverse / mpCamera2, kfView describes the NLeft left features with
+    // desc = all of mDescriptors, and the indices written to the graph are idx + NLeft (:820).
+    // The search result of every map point is computed first; the
     // loop below then replays :699-849 in list order with the CURRENT graph state (isBad / IsInKeyFrame may have
     // changed through an earlier Replace), exactly like the reference.  `frustum` carries the key frame's pose and
     // pinhole intrinsics (GetPose / GetTranslationInverse), mbf, mfLogScaleFactor, mnScaleLevels, image bounds.
     template <class KeyFramePtr, class MapPointPtr, class DescOfKF, class DescOfMP>
     static int Fuse(orbfe_handle* h, KeyFramePtr pKF, const std::vector<MapPointPtr>& vpMapPoints, const float th,
-                    const orbfe_frustum& frustum, const orbfe_frame_view& kfView, DescOfKF, DescOfMP descOfMP)
+                    const orbfe_frustum& frustum, const orbfe_frame_view& kfView, DescOfKF, DescOfMP descOfMP,
+                    const bool bRight = false)
     {
         const int M = (int)vpMapPoints.size();
         std::vector<orbfe_world_point> pts(M > 0 ? M : 1);
@@ -387,8 +394,13 @@ struct KeyFrameMatcher {
             std::memcpy(&mpd[(size_t)i * 32], descOfMP(pMP), 32);
         }
         std::vector<int> bestIdx(M > 0 ? M : 1), bestDist(M > 0 ? M : 1);
-        orbfe_detail::check(orbfe_fuse_search(h, &kfView, pKF->mvInvLevelSigma2.data(), pKF->mvuRight.data(), &frustum, th, M,
-                                              pts.data(), mpd.data(), bestIdx.data(), bestDist.data()), h, "orbfe_fuse_search");
+        if (bRight)
+            orbfe_detail::check(orbfe_fuse_search_right(h, &kfView, pKF->NRight, pKF->mvInvLevelSigma2.data(), pKF->mvuRight.data(),
+                                                        &frustum, th, M, pts.data(), mpd.data(), bestIdx.data(), bestDist.data()),
+                                h, "orbfe_fuse_search_right");
+        else
+            orbfe_detail::check(orbfe_fuse_search(h, &kfView, pKF->mvInvLevelSigma2.data(), pKF->mvuRight.data(), &frustum, th, M,
+                                                  pts.data(), mpd.data(), bestIdx.data(), bestDist.data()), h, "orbfe_fuse_search");
         int nFused = 0;
         for (int i = 0; i < M; i++) {
             const auto& pMP = vpMapPoints[i];

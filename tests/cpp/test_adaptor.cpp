@@ -48,7 +48,7 @@ struct MapPoint3D {  // the MapPoint members ORBmatcher::Fuse touches
 };
 
 struct KeyFrame {
-    int N = 0;
+    int N = 0, NLeft = -1, NRight = -1;
     std::shared_ptr<std::vector<KeyPoint>> mvKeysUn;
     std::vector<uint8_t> mDescriptors;
     std::map<unsigned, std::vector<unsigned>> mFeatVec;
@@ -70,7 +70,7 @@ struct RelocFrame {  // the Frame members the relocalisation overload writes
 };
 
 struct Frame {
-    int mNumKeypoints = 0;
+    int mNumKeypoints = 0, Nleft = -1;
     std::shared_ptr<std::vector<KeyPoint>> mvKeysUn;
     std::vector<uint8_t> mDescriptors;
     std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
@@ -214,6 +214,23 @@ int main(int argc, char** argv)
         const int nf = KeyFrameMatcher::Fuse(ex.handle(), kf, mpts, 3.0f, fr, kv, 0,
                                              [](const std::shared_ptr<MapPoint3D>& m) { return m->desc; });
         std::printf("triangulation n=%d self=%zu fuse=%d of %zu\n", nt, self, nf, mpts.size());
+        {   // Fuse(..., bRight = true) on a two-camera key frame whose right features are copies of the left ones seen
+            // from the same pose: the same map points fuse, with indices shifted by NLeft (:820)
+            auto kfr = std::make_shared<KeyFrame>(*kf);
+            kfr->NLeft = n; kfr->NRight = n; kfr->N = 2 * n;
+            kfr->mDescriptors.insert(kfr->mDescriptors.end(), desc.begin(), desc.end());
+            kfr->mvpMapPoints.assign(2 * (size_t)n, nullptr);
+            std::vector<std::shared_ptr<MapPoint3D>> fresh;
+            for (auto& m : mpts) { auto c = std::make_shared<MapPoint3D>(*m); c->bad = false; c->inKF.clear(); fresh.push_back(c); }
+            orbfe_frame_view kvr = kv;
+            kvr.desc = kfr->mDescriptors.data();
+            const int nfr = KeyFrameMatcher::Fuse(ex.handle(), kfr, fresh, 3.0f, fr, kvr, 0,
+                                                  [](const std::shared_ptr<MapPoint3D>& m) { return m->desc; }, true);
+            int shifted = 0, left = 0;
+            for (int i = 0; i < 2 * n; i++)
+                if (kfr->mvpMapPoints[i]) (i >= n ? shifted : left)++;
+            std::printf("fuse_right n=%d shifted=%d left=%d\n", nfr, shifted, left);
+        }
 
         // the remaining ORBmatcher statics on a key frame observed from its own pose (identity Sim3):
         // every 3rd keypoint owns a map point sitting exactly on it

@@ -118,6 +118,8 @@ def test_adaptor_matches_oracle(built, tmp_path):
     mt = re.search(r"triangulation n=(\d+) self=(\d+) fuse=(\d+) of (\d+)", stdout)
     assert mt and int(mt.group(1)) == nt and int(mt.group(2)) == int((m12 == np.arange(n_kp)).sum())
     assert int(mt.group(3)) > int(mt.group(4)) // 2  # most on-keypoint map points fuse
+    mr = re.search(r"fuse_right n=(\d+) shifted=(\d+) left=(\d+)", stdout)   # bRight: same matches, indices + NLeft
+    assert mr and int(mr.group(1)) == int(mt.group(3)) and int(mr.group(2)) > 0 and int(mr.group(3)) == 0
     assert "prep grey=1 grey2=1 same=1" in stdout  # ImagePreparer with identity maps reproduces the plain extraction
     # SearchBySim3 / Sim3 Fuse / relocalisation SearchByProjection on a key frame seen from its own pose
     ms = re.search(r"sim3 found=(\d+) same=(\d+) fuse3=(\d+) repl=(\d+) added=(\d+) reloc=(\d+) same=(\d+) slot0=(\d+)", stdout)
