@@ -701,20 +701,16 @@ __device__ __forceinline__ void wave_top2_u32(uint32_t& k1, uint32_t& k2)
 // window's grid columns (lane-strided) and reduces the two smallest free keys; all lanes get the result.
 // The claim test goes first: a starved map point sits in a region where nearly everything is taken.
 template <bool LDS, bool DESC, typename SLds>
-__device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, int i, const int* claim,
+__device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, int i, const MpWindow& w,
+                                                    const unsigned long long (&d4)[4], const int* cs, const int* claim,
                                                     const SLds* S, int lane, uint32_t& k1, uint32_t& k2)
 {
-    const MpWindow w = mp_window(A, A.mps[(size_t)f * A.M + i]);
     k1 = kKey32None;
     k2 = kKey32None;
     if (w.valid) {  // wave-uniform
         const int tabStride = A.g.cols + 1;
-        const int* cs = A.colStart + (size_t)f * A.tabLevels * tabStride;
         const int4* rec = A.rec + (size_t)f * A.kpStride;
         const unsigned long long* descS = A.descS + (size_t)f * A.kpStride * 4;
-        unsigned long long d4[4];
-        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * A.M + i) * 32);
-        d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
         for (int l = max(w.minLevel, 0); l <= w.maxLevel; l++) {
             const int* csl = cs + (size_t)l * tabStride;
             const int plo = csl[w.minCX], phi = csl[w.maxCX + 1];  // all rows of the window's columns
@@ -741,6 +737,11 @@ __device__ __forceinline__ void full_scan_top2_wave(const ProjArgs& A, int f, in
     wave_top2_u32(k1, k2);
 }
 
+// starved map points whose window + descriptor are parked in LDS by their own threads (one memory latency for all of
+// them) instead of being fetched by the rescanning wave, one after the other
+constexpr int kFbLds = 192;
+constexpr int kResTabLds = 1024;  // column-start tables up to this many entries are kept in LDS too
+
 // THREADS: 1024 for small launches (fewest ordered chunks: shortest call); 256 when the chip is full anyway -- a 1024-thread
 // block with its register and LDS footprint keeps a whole CU to itself while it mostly waits on barriers.
 template <bool LDS, int THREADS, int N = kResN, bool DESC = false>
@@ -752,6 +753,9 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
     __shared__ int sFbCount[2];                          // starved map points of the current sweep (by sweep parity, like sChanged)
     __shared__ int sFbMp[THREADS];
     __shared__ uint32_t sFbK1[THREADS], sFbK2[THREADS];
+    __shared__ MpWindow sFbWin[kFbLds];
+    __shared__ unsigned long long sFbDesc[kFbLds][4];
+    __shared__ int sTab[LDS ? kResTabLds : 1];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     const int n = min(A.nKp[f], A.kpStride);
@@ -787,6 +791,12 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
         const unsigned long long* dsrc = A.descS + (size_t)f * A.kpStride * 4;
         for (int q = tid; q < n * 4; q += THREADS) S.desc[q] = dsrc[q];
     }
+    const int tabStride = A.g.cols + 1;
+    const int* csG = A.colStart + (size_t)f * A.tabLevels * tabStride;
+    const bool tabInLds = LDS && A.tabLevels * tabStride <= kResTabLds;  // block-uniform
+    if (tabInLds)
+        for (int k = tid; k < A.tabLevels * tabStride; k += THREADS) sTab[k] = csG[k];
+    const int* cs = tabInLds ? sTab : csG;
     if (tid == 0) sCount = 0;
     int nAccepted = 0;
     __syncthreads();  // claim tables and LDS image complete before the first sweep
@@ -847,6 +857,12 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
                     if (!decided) {  // exact rescan, done cooperatively below
                         slot = atomicAdd(&sFbCount[iter & 1], 1);
                         sFbMp[slot] = i;
+                        if (slot < kFbLds) {
+                            sFbWin[slot] = mp_window(A, mps[i]);
+                            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * M + i) * 32);
+#pragma unroll
+                            for (int t = 0; t < 4; t++) sFbDesc[slot][t] = dp[t];
+                        }
                         atomicAdd(&A.dbg[f * 4 + 1], 1);
                     }
                 }
@@ -884,9 +900,24 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
             __syncthreads();
             if (sFbCount[iter & 1] > 0) {  // block-uniform, rare: some stored list ran dry undecided -- exact rescan, one wave per map point
                 const int nFb = sFbCount[iter & 1];
-                for (int q = tid >> 6; q < nFb; q += THREADS / 64) {
+                // (four map points per wave on 16-lane rows was measured: 0.355 ms against 0.324 -- a sweep rarely holds more
+                // starved map points than the block has waves, and a row needs four times the iterations per window)
+                for (int q = __builtin_amdgcn_readfirstlane(tid >> 6); q < nFb; q += THREADS / 64) {
                     uint32_t a1, a2;
-                    full_scan_top2_wave<LDS, DESC>(A, f, sFbMp[q], claim, &S, tid & 63, a1, a2);
+                    const int mp = sFbMp[q];
+                    MpWindow w;
+                    unsigned long long d4[4];
+                    if (q < kFbLds) {
+                        w = sFbWin[q];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) d4[t] = sFbDesc[q][t];
+                    } else {
+                        w = mp_window(A, mps[mp]);
+                        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.mpDesc + ((size_t)f * M + mp) * 32);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) d4[t] = dp[t];
+                    }
+                    full_scan_top2_wave<LDS, DESC>(A, f, mp, w, d4, cs, claim, &S, tid & 63, a1, a2);
                     if ((tid & 63) == 0) { sFbK1[q] = a1; sFbK2[q] = a2; }
                 }
                 __syncthreads();
