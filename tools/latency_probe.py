@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(ROOT, "orb_slam3_v1.0_amd", "python")); sys.path
 import numpy as np
 import orbfe, bench
 from orbfe import synth
+if os.environ.get("ORBFE_PROBE_LIB"):   # A/B of two builds
+    orbfe.LIB_PATH = os.path.abspath(os.environ["ORBFE_PROBE_LIB"])
 for wl in ("euroc_752x480", "batched_1280x720", "tumvi_1024x1024"):
     cfg = bench.WORKLOADS[wl]
     ex = orbfe.ORBextractor(*cfg, device=0, max_batch=1)
