@@ -499,11 +499,14 @@ def main():
         if not a.no_host_io and world == 1 and scaling == "weak":
             slot = min(256, B)
             try:
-                out["value_host_io"] = host_io_rate(ex, frames_sets[0], slot, 4, True)
-                out["value_host_io_pageable"] = host_io_rate(ex, frames_sets[0], slot, 2, False)
+                # long enough (>= 0.1 s) that filling and draining the three-slot ring is a few per cent of the timed region
+                out["value_host_io"] = host_io_rate(ex, frames_sets[0], slot, 40, True)
+                out["value_host_io_pageable"] = host_io_rate(ex, frames_sets[0], slot, 20, False)
                 out["host_io"] = {"unit": "frames/s", "what": "extract only, host pointers in (pinned / pageable numpy rows) and out, "
                                   "ring of 3 slots x %d frames, H2D || kernels || D2H on three streams" % slot,
-                                  "pcie_ceiling_frames_per_s": 63e9 / (W * H + 60 * n_kp_mean)}
+                                  # PCIe Gen5 x16, 63 GB/s per direction, full duplex: the upload (W*H bytes per frame) is the
+                                  # larger direction (the ring downloads the padded result block: cap * 56 B per frame)
+                                  "pcie_ceiling_frames_per_s": 63e9 / (W * H)}
             except orbfe.OrbfeError as e:  # report, do not lose the headline line
                 out["host_io"] = {"error": str(e)}
         if a.texture_sweep and world == 1:

@@ -902,7 +902,7 @@ int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch
             }
         }
     }
-    const int inPitch = direct ? pitch : h->dInPitch;
+    int stagedPitch = h->dInPitch;
     size_t frameStride = st->inFrame;
     if (direct) {
         // pinned sources: DMA straight from the caller's memory.  Frames that sit at a constant distance (a packed
@@ -920,21 +920,31 @@ int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch
                 HIPCHK(h, hipMemcpyAsync(sl.dIn + b * st->inFrame, grays[b], std::min(bytes, st->inFrame), hipMemcpyHostToDevice, st->sIn));
         }
     } else {
-        const int dp = h->dInPitch;
+        // pageable sources go through the slot's pinned staging block on a pool of copy threads.  A dword-aligned source
+        // pitch is kept (the kernels read it as it is), so a band of rows is ONE contiguous copy; other pitches are
+        // re-pitched row by row.
+        const bool keep = (pitch & 3) == 0 && pitch <= h->dInPitch;
+        const int dp = keep ? pitch : h->dInPitch;
         const size_t inFrame = st->inFrame;
         uint8_t* hIn = sl.hIn;
-        // 4 row bands per frame so that a handful of frames still spreads over the pool
-        const int bands = 4;
+        const int bands = 4;  // row bands per frame so that a handful of frames still spreads over the pool
         st->pool->parallel_for(n * bands, [&](int job) {
             const int b = job / bands, band = job - b * bands;
             const int y0 = H * band / bands, y1 = H * (band + 1) / bands;
-            for (int y = y0; y < y1; y++) memcpy(hIn + b * inFrame + (size_t)y * dp, grays[b] + (size_t)y * pitch, (size_t)W);
+            if (keep) {
+                const size_t bytes = (size_t)(y1 - y0 - 1) * pitch + (size_t)W;
+                memcpy(hIn + b * inFrame + (size_t)y0 * dp, grays[b] + (size_t)y0 * pitch, bytes);
+            } else {
+                for (int y = y0; y < y1; y++) memcpy(hIn + b * inFrame + (size_t)y * dp, grays[b] + (size_t)y * pitch, (size_t)W);
+            }
         });
+        stagedPitch = dp;
         HIPCHK(h, hipMemcpyAsync(sl.dIn, sl.hIn, st->inFrame * (size_t)n, hipMemcpyHostToDevice, st->sIn));
     }
     HIPCHK(h, hipEventRecord(sl.evIn, st->sIn));
     // kernels on the handle's stream, behind the upload
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.evIn, 0));
+    const int inPitch = direct ? pitch : stagedPitch;
     const int rc = extract_chain(h, sl.dIn, frameStride, inPitch, n, reinterpret_cast<orbfe_keypoint*>(sl.dOut + st->offKp),
                                  sl.dOut + st->offDesc, reinterpret_cast<int*>(sl.dOut), reinterpret_cast<int*>(sl.dOut + st->offPer),
                                  reinterpret_cast<int*>(sl.dOut + st->offStatus), h->stream);

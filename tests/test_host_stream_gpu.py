@@ -47,8 +47,11 @@ def test_stream_ring_matches_batched_path(built):
     pinned = torch.from_numpy(frames).pin_memory()
     padded = torch.zeros((n_frames, H, W + 8), dtype=torch.uint8).pin_memory()  # pitch W + 8 (4-aligned), pinned
     padded[:, :, :W] = torch.from_numpy(frames)
+    odd = np.zeros((n_frames, H, W + 2), np.uint8)   # pitch W + 2: not dword-aligned -> re-pitched row by row
+    odd[:, :, :W] = frames
     sources = {
         "pageable": (frames, W),
+        "pageable_odd_pitch": (odd, W + 2),
         "pinned_packed": (pinned.numpy(), W),
         "pinned_padded_pitch": (padded.numpy(), W + 8),
     }
