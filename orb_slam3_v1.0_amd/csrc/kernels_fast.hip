@@ -138,31 +138,32 @@ __device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* addr, uint32_t v)
 
 // One compaction step of stage A, hand-scheduled (hipcc turns the same source into 9 vector instructions per step:
 // it rebuilds the ballot through v_cndmask + v_cmp and masks the 16-bit half before comparing it).  The lanes whose
-// 16-bit half of d (HIGH: bits 31..16) is negative and that are valid in both lane masks append `entry` to the queue
+// 16-bit half of the margin m (HIGH: bits 31..16) exceeds th and that are valid in both lane masks append their half of
+// entryPair (the staged byte offsets of the two positions) to the queue
 // at byte address qNext + rank * step; returns how many did.  EXEC is narrowed and restored inside the statement.
 template <bool HIGH>
-__device__ __forceinline__ int queue_slot(uint32_t d, unsigned long long colMask, unsigned long long rowMask, uint32_t entry,
+__device__ __forceinline__ int queue_slot(uint32_t m, int th, unsigned long long colMask, unsigned long long rowMask, uint32_t entryPair,
                                           int stepV, int qNext)
 {
     unsigned long long save;
     uint32_t tmp;
     int cnt;
     if constexpr (HIGH)
-        asm volatile("v_cmp_gt_i32_e32 vcc, 0, %3\n\t"
+        asm volatile("v_cmp_lt_i32_sdwa vcc, %9, sext(%3) src0_sel:DWORD src1_sel:WORD_1\n\t"
                      "s_and_b64 vcc, vcc, %4\n\t"
                      "s_and_b64 vcc, vcc, %5\n\t"
                      "s_and_saveexec_b64 %0, vcc\n\t"
                      "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
                      "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
                      "v_mad_i32_i24 %1, %1, %7, %8\n\t"
-                     "ds_write_b16 %1, %6\n\t"
+                     "ds_write_b16_d16_hi %1, %6\n\t"
                      "s_mov_b64 exec, %0\n\t"
                      "s_bcnt1_i32_b64 %2, vcc"
                      : "=&s"(save), "=&v"(tmp), "=s"(cnt)
-                     : "v"(d), "s"(colMask), "s"(rowMask), "v"(entry), "v"(stepV), "s"(qNext)
+                     : "v"(m), "s"(colMask), "s"(rowMask), "v"(entryPair), "v"(stepV), "s"(qNext), "s"(th)
                      : "vcc", "scc", "memory");
     else
-        asm volatile("v_cmp_gt_i16_e32 vcc, 0, %3\n\t"
+        asm volatile("v_cmp_lt_i16_e32 vcc, %9, %3\n\t"
                      "s_and_b64 vcc, vcc, %4\n\t"
                      "s_and_b64 vcc, vcc, %5\n\t"
                      "s_and_saveexec_b64 %0, vcc\n\t"
@@ -173,7 +174,7 @@ __device__ __forceinline__ int queue_slot(uint32_t d, unsigned long long colMask
                      "s_mov_b64 exec, %0\n\t"
                      "s_bcnt1_i32_b64 %2, vcc"
                      : "=&s"(save), "=&v"(tmp), "=s"(cnt)
-                     : "v"(d), "s"(colMask), "s"(rowMask), "v"(entry), "v"(stepV), "s"(qNext)
+                     : "v"(m), "s"(colMask), "s"(rowMask), "v"(entryPair), "v"(stepV), "s"(qNext), "s"(th)
                      : "vcc", "scc", "memory");
     return cnt;
 }
@@ -415,8 +416,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             ca[i] = __builtin_amdgcn_perm(0u, d1, 0x0c010c00u);
             cb[i] = __builtin_amdgcn_perm(0u, d1, 0x0c030c02u);
         }
-        const uint32_t thPk = (uint32_t)minTh * 0x00010001u;
-        uint32_t dneg[kStripRows][2];  // sign bit of a half set <=> that position passes
+        uint32_t marg[kStripRows][2];  // per 16-bit half: max(bright, dark) margin of that position; it passes iff > minTh
 #pragma unroll
         for (int i = 0; i < kStripRows; i++) {
             const uint8_t* rp = base + (i + 3) * kImgW;
@@ -433,8 +433,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                 const uint32_t e = p ? eb : ea, wq = p ? wb : wa;
                 const uint32_t hiPair = pk_min_u(pk_max_u(n, so), pk_max_u(e, wq));
                 const uint32_t loPair = pk_max_u(pk_min_u(n, so), pk_min_u(e, wq));
-                const uint32_t m = pk_max_i(pk_sub(hiPair, c), pk_sub(c, loPair));
-                dneg[i][p] = pk_sub(thPk, m);
+                marg[i][p] = pk_max_i(pk_sub(hiPair, c), pk_sub(c, loPair));
             }
         }
         // validity of the lane's 4 columns / 5 rows as lane masks: staged column c is tested iff cLo <= c <= cHi
@@ -457,13 +456,14 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         const int qBase = (int)(reinterpret_cast<uintptr_t>(&sQA[0]) & 0xffffu);  // LDS byte address of the queue
         int qNext = qBase + (wv ? 2 * (kQCap - 1) : 0);
         uint32_t nq = 0;
+        const uint32_t e0Pair = (uint32_t)e0 * 0x00010001u + 0x00010000u;  // offsets of columns (0, 1) as a 16-bit pair (< 2^16: no carry)
 #pragma unroll
         for (int i = 0; i < kStripRows; i++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t entry = (uint32_t)(e0 + i * kImgW + j);
-                const int cnt = (j & 1) ? queue_slot<true>(dneg[i][j >> 1], colOK[j], rowOK[i], entry, qStepV, qNext)
-                                        : queue_slot<false>(dneg[i][j >> 1], colOK[j], rowOK[i], entry, qStepV, qNext);
+                const uint32_t entryPair = e0Pair + (uint32_t)(i * kImgW + (j & 2)) * 0x00010001u;  // one add per column pair
+                const int cnt = (j & 1) ? queue_slot<true>(marg[i][j >> 1], minTh, colOK[j], rowOK[i], entryPair, qStepV, qNext)
+                                        : queue_slot<false>(marg[i][j >> 1], minTh, colOK[j], rowOK[i], entryPair, qStepV, qNext);
                 nq += (uint32_t)cnt;
                 qNext += cnt * qStep;
             }
