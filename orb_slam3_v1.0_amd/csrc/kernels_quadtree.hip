@@ -148,7 +148,7 @@ __device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const Le
 __host__ __device__ constexpr size_t qt_scratch_bytes(int nc) { return (size_t)nc * (8 + 8 + 8 + 4 + 4 + 16 + 4 + 4 + 4 + 1 + 1); }
 
 template <int NC, bool GLOBAL>
-__global__ __launch_bounds__(kQtThreads) void quadtree_kernel(const PipelineDesc* __restrict__ P,
+__global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <= 512 ? 8 : 1))) void quadtree_kernel(const PipelineDesc* __restrict__ P,
                                                              const uint32_t* __restrict__ cand,
                                                              uint16_t* __restrict__ nodeOfAll,
                                                              uint32_t* __restrict__ counters,
