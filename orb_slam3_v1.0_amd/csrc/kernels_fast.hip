@@ -127,6 +127,42 @@ __device__ __forceinline__ unsigned long long mask_le_u32(uint32_t x, uint32_t b
     return m;
 }
 
+__device__ __forceinline__ unsigned long long mask_ge_u32(uint32_t x, uint32_t bound)
+{
+    unsigned long long m;
+    asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "s"(bound));
+    return m;
+}
+__device__ __forceinline__ unsigned long long mask_gt_u32(uint32_t a, uint32_t b)
+{
+    unsigned long long m;
+    asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+// per lane: mask bit set ? a : b
+__device__ __forceinline__ uint32_t select_by_mask(unsigned long long mask, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+// LDS operations of the lanes of `mask` only (EXEC narrowed and restored inside the statement; addresses are LDS bytes)
+__device__ __forceinline__ void masked_lds_add(unsigned long long mask, uint32_t addr, uint32_t v)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void masked_lds_write_b32(unsigned long long mask, uint32_t addr, uint32_t v)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+}
+// LDS add without a return value, issued by the calling lane(s) as written
+__device__ __forceinline__ void lds_add(uint32_t* addr, uint32_t v)
+{
+    asm volatile("ds_add_u32 %0, %1" : : "v"((uint32_t)(uintptr_t)addr), "v"(v) : "memory");
+}
+
 // LDS fetch-add issued by the calling lane(s) as written (hipcc's atomic optimizer wraps a single-lane atomicAdd in a
 // wave reduction)
 __device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* addr, uint32_t v)
@@ -528,48 +564,54 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int nB = (MODE & 8) ? 0 : (int)sQ[2];
 
     // ---- NMS (strictly greater than all 8 neighbours, Fast_gpu.cu:300-310) + tile compaction,
-    //      again over the dense corner queue; halo corners only serve as neighbours ----
+    //      again over the dense corner queue; halo corners only serve as neighbours.  The predicates live as lane masks
+    //      in scalar registers from the compare on (a ballot of a combined predicate, and a one-lane atomicAdd behind
+    //      hipcc's atomic optimizer, cost a dozen vector instructions each); the three plain counts are summed per
+    //      wave on the scalar unit and reach LDS once, after the loop ----
     {
+        uint32_t nPreW = 0, nPreHiW = 0, nKeepHiW = 0;
+        const uint32_t rowLds = (uint32_t)(uintptr_t)&sRow[0];
+        const uint32_t candLds = (uint32_t)(uintptr_t)&sCand[0];
+        constexpr uint32_t kIdleEntry = (uint32_t)(20 * kImgW + 36);  // an interior position: inactive lanes read valid LDS
 #pragma unroll 1
-        for (int i = tid; i < ((nB + 63) & ~63); i += 256) {
-            bool pre = false, keep = false, hi = false;
-            int ox = 0, oy = 0, s = 0;
-            if (i < nB) {
-                const uint32_t e = sQB[i];
-                const uint32_t r = (e * 3641u) >> 18;  // e / 72 for e < 2952
-                ox = (int)(e - r * kImgW) - 4;
-                oy = (int)r - 4;
-                pre = ox >= 0 && ox < kFastTW && oy >= 0 && oy < kFastTH;  // interior: counted once
-                if (pre) {
-                    const uint8_t* sp = &sScore[0][0] + (e - kScoreOfs);
-                    s = sp[0];
-                    hi = s >= iniTh;
-                    atomicAdd(&sRow[oy], hi ? 0x10001u : 1u);  // only read by the exact-cap path of the quadtree kernel
-                    // strictly greater than all eight == greater than their maximum (three v_max3 + one v_max)
-                    const int n0 = max(max((int)sp[-kScPitch - 1], (int)sp[-kScPitch]), (int)sp[-kScPitch + 1]);
-                    const int n1 = max(max((int)sp[-1], (int)sp[1]), (int)sp[kScPitch - 1]);
-                    const int n2 = max((int)sp[kScPitch], (int)sp[kScPitch + 1]);
-                    keep = s > max(max(n0, n1), n2);
-                }
-            }
-            const unsigned long long mPre = __builtin_amdgcn_ballot_w64(pre);
+        for (int i0 = wv * 64; i0 < nB; i0 += 256) {  // wave-uniform
+            const int i = i0 + lane;
+            uint32_t e = kIdleEntry;
+            if (i < nB) e = sQB[i];
+            const unsigned long long mAct = mask_le_u32((uint32_t)i, (uint32_t)(nB - 1));
+            const uint32_t r = (e * 3641u) >> 18;  // e / 72 for e < 2952
+            const uint32_t ox = e - r * kImgW - 4u, oy = r - 4u;   // unsigned: positions left of / above the tile wrap
+            // interior (counted once): 0 <= ox < kFastTW, 0 <= oy < kFastTH
+            const unsigned long long mPre = mAct & mask_le_u32(ox, kFastTW - 1) & mask_le_u32(oy, kFastTH - 1);
             if (mPre == 0) continue;  // wave-uniform
-            const unsigned long long mPreHi = __builtin_amdgcn_ballot_w64(pre && hi);
-            const unsigned long long mKeep = __builtin_amdgcn_ballot_w64(keep);
-            const unsigned long long mKeepHi = __builtin_amdgcn_ballot_w64(keep && hi);
-            uint32_t wbase = 0;
-            if (lane == 0) {
-                atomicAdd(&sCnt[2], (uint32_t)__popcll(mPre));
-                if (mPreHi) atomicAdd(&sCnt[3], (uint32_t)__popcll(mPreHi));
-                if (mKeepHi) atomicAdd(&sCnt[1], (uint32_t)__popcll(mKeepHi));
-                if (mKeep) wbase = atomicAdd(&sCnt[0], (uint32_t)__popcll(mKeep));
-            }
-            wbase = __builtin_amdgcn_readfirstlane(wbase);
-            if (keep) {
-                const uint32_t rank = (uint32_t)__popcll(mKeep & ((1ull << lane) - 1ull));
-                sCand[wbase + rank] = pack_cand(x0 + ox, y0 + oy, s);
+            const uint8_t* sp = &sScore[0][0] + (e - kScoreOfs);
+            const uint32_t sc = sp[0];
+            const uint32_t n0 = max(max((uint32_t)sp[-kScPitch - 1], (uint32_t)sp[-kScPitch]), (uint32_t)sp[-kScPitch + 1]);
+            const uint32_t n1 = max(max((uint32_t)sp[-1], (uint32_t)sp[1]), (uint32_t)sp[kScPitch - 1]);
+            const uint32_t n2 = max((uint32_t)sp[kScPitch], (uint32_t)sp[kScPitch + 1]);
+            const uint32_t nmax = max(max(n0, n1), n2);  // strictly greater than all eight == greater than their maximum
+            const unsigned long long mHi = mask_ge_u32(sc, (uint32_t)iniTh);
+            const unsigned long long mKeep = mPre & mask_gt_u32(sc, nmax);
+            const unsigned long long mPreHi = mPre & mHi, mKeepHi = mKeep & mHi;
+            nPreW += (uint32_t)__popcll(mPre);
+            nPreHiW += (uint32_t)__popcll(mPreHi);
+            nKeepHiW += (uint32_t)__popcll(mKeepHi);
+            // pre-NMS corners per tile row (only read by the exact-cap path of the quadtree kernel): low | high << 16
+            masked_lds_add(mPre, rowLds + 4u * oy, select_by_mask(mHi, 0x10001u, 1u));
+            if (mKeep) {  // wave-uniform
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = lds_add_rtn(&sCnt[0], (uint32_t)__popcll(mKeep));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mKeep >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mKeep, 0u));
+                masked_lds_write_b32(mKeep, candLds + 4u * (wbase + rank), pack_cand(x0 + (int)ox, y0 + (int)oy, (int)sc));
             }
         }
+        if (lane == 0) {
+            if (nPreW) lds_add(&sCnt[2], nPreW);
+            if (nPreHiW) lds_add(&sCnt[3], nPreHiW);
+            if (nKeepHiW) lds_add(&sCnt[1], nKeepHiW);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS operations above are not counted by the compiler
     }
     __syncthreads();
 
