@@ -157,6 +157,42 @@ __device__ __forceinline__ void masked_lds_write_b32(unsigned long long mask, ui
     unsigned long long save;
     asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
 }
+// lane masks of a < b (signed; the bound is a scalar, or a vector with `vbound`)
+__device__ __forceinline__ unsigned long long mask_lt_i32(uint32_t a, int b, bool vbound = false)
+{
+    unsigned long long m;
+    if (vbound) asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    else asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
+    return m;
+}
+// lane masks of th < (signed 16-bit low / high half of m)
+__device__ __forceinline__ unsigned long long mask_th_lo(int th, uint32_t m)
+{
+    unsigned long long r;
+    asm("v_cmp_lt_i16_e64 %0, %1, %2" : "=s"(r) : "s"(th), "v"(m));
+    return r;
+}
+__device__ __forceinline__ unsigned long long mask_th_hi(int th, uint32_t m)
+{
+    unsigned long long r;
+    asm("v_cmp_lt_i32_sdwa %0, %1, sext(%2) src0_sel:DWORD src1_sel:WORD_1" : "=s"(r) : "s"(th), "v"(m));
+    return r;
+}
+__device__ __forceinline__ void masked_lds_write_b8(unsigned long long mask, uint32_t addr, uint32_t v)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void masked_lds_write_b8_hi(unsigned long long mask, uint32_t addr, uint32_t v)  // bits 23..16 of v
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8_d16_hi %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void masked_lds_write_b16(unsigned long long mask, uint32_t addr, uint32_t v)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+}
 // LDS add without a return value, issued by the calling lane(s) as written
 __device__ __forceinline__ void lds_add(uint32_t* addr, uint32_t v)
 {
@@ -516,6 +552,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         const int np0 = (n0 + 1) >> 1, npT = np0 + ((n1 + 1) >> 1);
         const uint32_t* qd = reinterpret_cast<const uint32_t*>(sQA);
         const uint8_t* img = &sImg[0][0];
+        const uint32_t scoreLds = (uint32_t)(uintptr_t)&sScore[0][0] - (uint32_t)kScoreOfs, qbLds = (uint32_t)(uintptr_t)&sQB[0];
 #pragma unroll 1
         for (int q0 = wv * 64; q0 < npT; q0 += 256) {   // wave-uniform trip count
             const int q = q0 + lane;
@@ -524,11 +561,10 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             // wave 0's pair q = slots 2q, 2q+1; wave 1's pair q' = slots kQCap-1-2q', kQCap-2-2q' = dword kQCap/2-1-q'
             uint32_t e01 = act ? qd[seg1 ? kQCap / 2 - 1 - (q - np0) : q] : (uint32_t)kScoreOfs * 0x00010001u;
             if (seg1) e01 = __builtin_amdgcn_alignbit(e01, e01, 16);  // first entry of the pair in the low half
-            const bool two = seg1 ? 2 * (q - np0) + 1 < n1 : 2 * q + 1 < n0;  // false for inactive lanes too
+            // second pixel of the pair present?  (false for inactive lanes too)
+            const unsigned long long mask_two = mask_lt_i32((uint32_t)(seg1 ? 2 * (q - np0) + 1 : 2 * q + 1), seg1 ? n1 : n0, true);
             const uint32_t eA = e01 & 0xffffu;
-            const uint32_t eB = two ? e01 >> 16 : eA;
-            // a lane (half) without a pixel never passes: its threshold is the largest 16-bit value
-            const int thA = act ? minTh : 0x7fff, thB = two ? minTh : 0x7fff;
+            const uint32_t eB = select_by_mask(mask_two, e01 >> 16, eA);
             const uint8_t* pa = img + eA;  // centre of pixel A in the staged tile
             const uint8_t* pb = img + eB;
             // ring position k <-> (dy, dx): 0:(3,0) 1:(3,1) 2:(2,2) 3:(1,3) 4:(0,3) 5:(-1,3) 6:(-2,2) 7:(-3,1) 8:(-3,0)
@@ -542,23 +578,27 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             const uint32_t hi = pk_sub(arc_extreme<false>(p), v);
             const uint32_t lo = pk_sub(v, arc_extreme<true>(p));
             const uint32_t margin = pk_max_i(hi, lo);
-            const int mA = (short)(margin & 0xffffu), mB = (int)margin >> 16;
-            const bool cornerA = mA > thA;
-            const bool cornerB = mB > thB;
-            if (cornerA) sScore[0][eA - kScoreOfs] = (uint8_t)(mA - 1);
-            if (cornerB) sScore[0][eB - kScoreOfs] = (uint8_t)(mB - 1);
+            // corners as lane masks straight from the compares (low half: 16-bit compare, high half through SDWA); a lane
+            // (half) without a pixel is masked out
+            const unsigned long long ma = mask_lt_i32((uint32_t)q, npT) & mask_th_lo(minTh, margin);
+            const unsigned long long mb = mask_two & mask_th_hi(minTh, margin);
+            // score - 1 of both halves with one subtraction: ds_write_b8 stores bits 7..0, ds_write_b8_d16_hi bits 23..16
+            const uint32_t sc1 = pk_sub(margin, 0x00010001u);
+            masked_lds_write_b8(ma, scoreLds + eA, sc1);
+            masked_lds_write_b8_hi(mb, scoreLds + eB, sc1);
             // corner queue: one reservation per wave for both halves
-            const unsigned long long ma = __builtin_amdgcn_ballot_w64(cornerA), mb = __builtin_amdgcn_ballot_w64(cornerB);
             const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
             if (na + nb) {  // wave-uniform
                 uint32_t qb = 0;
                 if (lane == 0) qb = lds_add_rtn(&sQ[2], na + nb);
                 qb = __builtin_amdgcn_readfirstlane(qb);
-                if (cornerA) sQB[__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u)) + qb] = (uint16_t)eA;
-                if (cornerB)
-                    sQB[__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u)) + (qb + na)] = (uint16_t)eB;
+                const uint32_t ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+                const uint32_t rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+                masked_lds_write_b16(ma, qbLds + 2u * (qb + ra), eA);
+                masked_lds_write_b16(mb, qbLds + 2u * (qb + na + rb), eB);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the masked LDS stores above are not counted by the compiler
     }
     __syncthreads();
     const int nB = (MODE & 8) ? 0 : (int)sQ[2];
