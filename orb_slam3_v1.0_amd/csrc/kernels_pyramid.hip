@@ -177,6 +177,7 @@ constexpr int kPyrWaves = 4;    // waves (independent tasks) per block
 
 constexpr int kPyrRows = 7;     // source rows staged per step of 4 output rows
 constexpr int kPyrSegDw = 96;   // dwords per staged row segment (256 output columns)
+constexpr int kPyrStride = 128; // dwords between staged rows in LDS: both halves of a row are stored by all 64 lanes
 
 
 // a * w + c with the 24-bit multiplier (a < 2^19, w <= 8192 scalar); hipcc splits the expression into two multiplies
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
                                                                  int gray0Pitch, uint8_t* __restrict__ ws,
                                                                  const uint32_t* __restrict__ tabs)
 {
-    __shared__ uint32_t sRows[kPyrWaves][kPyrRows][kPyrSegDw];  // wave-private: no block barrier
+    __shared__ uint32_t sRows[kPyrWaves][kPyrRows][kPyrStride];  // wave-private: no block barrier
 
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -250,10 +251,17 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
                 wp[i] = (2048u - wx) | (wx << 16);
             }
             const int nvalid = min(4, dw - x0);
-            const uint32_t ldA = segBase + 4u * (uint32_t)lane, ldB = ldA + 256u;  // the lane's two dwords of a staged row
-            const bool hasB = lane < kPyrSegDw - 64;
+            // The scalar unit is this kernel's busiest issue port, so nothing below is predicated per lane: lanes without a
+            // second dword (and, for the stores, lanes past the level width) use a byte offset beyond the buffer -- the
+            // range check drops the access -- instead of an EXEC mask and a branch around every load and store.
+            constexpr uint32_t kNowhere = 0x7ffffff0u;
+            const uint32_t ldA = segBase + 4u * (uint32_t)lane;  // the lane's two dwords of a staged row
+            const uint32_t ldB = lane < kPyrSegDw - 64 ? ldA + 256u : kNowhere;
+            const uint32_t stX = colOk ? (uint32_t)x0 : kNowhere;
+            const bool partial = (dw & 3) != 0;  // the level's last column group is narrower than a dword (wave-uniform)
 
             const int ys = strip * R, ye = min(ys + R, dh);
+            const uint32_t roMax = (uint32_t)((sh - 1) * spitch);
             uint32_t kRound = 1u << 23;
             asm("" : "+v"(kRound));  // in a vector register: v_mad_u32_u24 takes one scalar operand (the weight)
             // software pipeline: the global loads (and row-table entries) of step n + 1 are requested before step n is
@@ -261,17 +269,21 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
             uint32_t ytN[4];
             uint32_t ga[kPyrRows], gb[kPyrRows];
             auto request = [&](int yb) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) ytN[k] = ytab[min(yb + k, ye - 1)];
-                const int rN = (int)(ytN[0] & 0xffffu);
+                // four row-table entries with one scalar load: strips start at multiples of four rows and the table is
+                // padded to a multiple of four with copies of its last entry (rows past the strip are computed, not stored)
+                const uint4 y4 = *reinterpret_cast<const uint4*>(ytab + yb);
+                ytN[0] = y4.x; ytN[1] = y4.y; ytN[2] = y4.z; ytN[3] = y4.w;
+                uint32_t ro = (ytN[0] & 0xffffu) * (uint32_t)spitch;
 #pragma unroll
                 for (int j = 0; j < kPyrRows; j++) {
-                    const uint32_t ro = (uint32_t)(min(rN + j, sh - 1) * spitch);
-                    ga[j] = __builtin_amdgcn_raw_buffer_load_b32(srsrc, ldA, ro, 0);
-                    gb[j] = hasB ? __builtin_amdgcn_raw_buffer_load_b32(srsrc, ldB, ro, 0) : 0u;
+                    const uint32_t roc = min(ro, roMax);
+                    ga[j] = __builtin_amdgcn_raw_buffer_load_b32(srsrc, ldA, roc, 0);
+                    gb[j] = __builtin_amdgcn_raw_buffer_load_b32(srsrc, ldB, roc, 0);
+                    ro += (uint32_t)spitch;
                 }
             };
             request(ys);
+            uint32_t stRow = (uint32_t)(ys * dpitch);
 #pragma unroll 1
             for (int yb = ys; yb < ye; yb += 4) {
                 uint32_t yt[4];
@@ -280,15 +292,15 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
                 const int rA = (int)(yt[0] & 0xffffu);  // first staged source row
 #pragma unroll
                 for (int j = 0; j < kPyrRows; j++) {
-                    ring[j * kPyrSegDw + lane] = ga[j];
-                    if (hasB) ring[j * kPyrSegDw + 64 + lane] = gb[j];
+                    ring[j * kPyrStride + lane] = ga[j];
+                    ring[j * kPyrStride + 64 + lane] = gb[j];
                 }
                 if (yb + 4 < ye) request(yb + 4);  // wave-uniform
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int jt = (int)(yt[k] & 0xffffu) - rA;  // staged row of the top taps (scalar), bottom = jt + 1
-                    const uint32_t* wt = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ring + jt * kPyrSegDw) + winOff);
-                    const uint32_t* wb = wt + kPyrSegDw;
+                    const uint32_t* wt = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ring + jt * kPyrStride) + winOff);
+                    const uint32_t* wb = wt + kPyrStride;
                     uint32_t hT[4], hB[4];
                     pyr_hpass(wt[0], wt[1], wt[2], sel, wp, hT);
                     pyr_hpass(wb[0], wb[1], wb[2], sel, wp, hB);
@@ -300,15 +312,19 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
                     const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u);
                     const uint32_t hi = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0703u);
                     const uint32_t outw = lo | (hi << 16);
-                    const int y = yb + k;
-                    if (y < ye && colOk) {
-                        if (nvalid == 4) {
-                            __builtin_amdgcn_raw_buffer_store_b32(outw, drsrc, (uint32_t)x0, (uint32_t)(y * dpitch), 0);  // 4-aligned
-                        } else {
-                            for (int i = 0; i < nvalid; i++)
-                                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(outw >> (8 * i)), drsrc, (uint32_t)(x0 + i), (uint32_t)(y * dpitch), 0);
+                    if (yb + k < ye) {  // wave-uniform
+                        if (!partial) {
+                            __builtin_amdgcn_raw_buffer_store_b32(outw, drsrc, stX, stRow, 0);  // 4-aligned
+                        } else if (colOk) {
+                            if (nvalid == 4) {
+                                __builtin_amdgcn_raw_buffer_store_b32(outw, drsrc, (uint32_t)x0, stRow, 0);
+                            } else {
+                                for (int i = 0; i < nvalid; i++)
+                                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(outw >> (8 * i)), drsrc, (uint32_t)(x0 + i), stRow, 0);
+                            }
                         }
                     }
+                    stRow += (uint32_t)dpitch;
                 }
             }
         }
@@ -367,7 +383,7 @@ void launch_pyramid_level(hipStream_t s, int frames, const PipelineDesc* dP, int
     // output rows per wave task: long strips amortise the per-task column setup when the launch fills the chip anyway,
     // one 4-row step per task keeps a small batch short (a task is a serial chain of steps)
     static const int envR = getenv("ORBFE_PYR_ROWS") ? atoi(getenv("ORBFE_PYR_ROWS")) : 0;
-    const int R = envR > 0 ? envR : frames >= 128 ? 8 : 4;
+    const int R = envR > 0 ? (envR + 3) & ~3 : frames >= 128 ? 8 : 4;  // strips start at multiples of four rows (x4 row-table loads)
     const int tasks = ((dh + R - 1) / R) * ((dw + 255) / 256);
     hipLaunchKernelGGL(pyramid_kernel, dim3(frames, (tasks + kPyrWaves - 1) / kPyrWaves), dim3(kPyrWaves * 64), 0, s, dP, level, R, gray0,
                        gray0FrameStride, gray0Pitch, ws, tabs);
