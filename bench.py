@@ -511,7 +511,7 @@ def main():
                 out["host_io"] = {"error": str(e)}
         if a.texture_sweep and world == 1:
             sweep = {"default": out["value"]}
-            for name, fn in (("low_texture", lambda w, h, n, i0: synth.stream(w, h, n, index0=i0, density=0.0002)),
+            for name, fn in (("low_texture", lambda w, h, n, i0: synth.lowtex_stream(w, h, n, index0=i0)),
                              ("pink_noise", lambda w, h, n, i0: synth.pink_stream(w, h, n, index0=i0))):
                 _, dg = gen_sets(fn)
                 state["gray"] = dg

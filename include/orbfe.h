@@ -22,7 +22,9 @@
  * DIFFERENT stream wait for it, so mixing streams (or a *_device call followed by a host-pointer
  * call) is safe; it does not make two calls run concurrently.
  *
- * Input contract of the image entry points: rows `pitch` bytes apart, pitch < 2^24; when the
+ * Input contract of the image entry points: rows `pitch` bytes apart, pitch < 2^24 and
+ * pitch * (height - 1) + ((width + 3) & ~3) < 0x7ffffff0 (frames are addressed with 32-bit byte
+ * offsets; larger ones are refused with ORBFE_ERR_INVALID_ARG); when the
  * base address, pitch and frame stride are multiples of 4 the kernels read whole dwords, i.e. up
  * to the 4-byte-rounded end of every row -- the buffer must extend to
  * pitch * (height - 1) + ((width + 3) & ~3) bytes per frame (any pitch >= that rounded width, or a
@@ -144,6 +146,14 @@ int orbfe_get_device_status(orbfe_handle *h, unsigned *flags_out);
  * 4-byte-aligned pitch are copied by the DMA engine straight from the caller's buffer; pageable
  * ones are re-pitched into the slot's pinned block by a small thread pool first.
  * Results are byte-identical to orbfe_extract_batch / orbfe_extract_batch_device.
+ * Source lifetime: a pinned source may still be read by the DMA engine AFTER submit has returned
+ * (pageable sources have been copied by then, but the caller cannot rely on which path ran):
+ * every source frame must stay valid and UNCHANGED until the submission that carried it has been
+ * collected -- a capture buffer recycled earlier gives torn frames and no error.
+ * Threading: an orbfe_stream and its handle are single-caller objects -- submit, collect, in_flight
+ * and destroy must come from one thread at a time (the ring counters and the copy pool are not
+ * synchronised between a submitting and a collecting thread); serialise them externally or keep the
+ * producer / consumer split on the caller's side of one thread.
  * ---------------------------------------------------------------------------------------- */
 typedef struct orbfe_stream orbfe_stream;
 int orbfe_stream_create(orbfe_handle *h, int slots, int slot_frames, orbfe_stream **out);
@@ -323,7 +333,10 @@ int orbfe_project_map_points_device(orbfe_handle *h, const orbfe_frustum *frustu
                                     const orbfe_world_point *d_points, orbfe_map_point *d_out,
                                     float *d_proj_xr, void *stream);
 
-/* what ORBmatcher::SearchForTriangulation derives from the two key-frame poses (src/ORBmatcher.cc:448-465) */
+/* what ORBmatcher::SearchForTriangulation derives from the two key-frame poses (src/ORBmatcher.cc:448-465).
+ * ABI note: the library reads the WHOLE struct as declared here (it grew a camera-model tail in round 2 and carries
+ * no size / version field): zero-initialise it (`orbfe_tri_params p = {0};`) and rebuild callers against this header --
+ * a caller compiled against the shorter round-1 layout would hand over a short buffer. */
 typedef struct orbfe_tri_params {
     float f12[9];           /* F12 = K1^-T [t12]x R12 K2^-1, row-major: the matrix Pinhole::epipolarConstrain
                              * rebuilds for every pair (src/CameraModels/Pinhole.cpp:106-109) */

@@ -150,12 +150,12 @@ __device__ __forceinline__ uint32_t select_by_mask(unsigned long long mask, uint
 __device__ __forceinline__ void masked_lds_add(unsigned long long mask, uint32_t addr, uint32_t v)
 {
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "scc", "memory");
 }
 __device__ __forceinline__ void masked_lds_write_b32(unsigned long long mask, uint32_t addr, uint32_t v)
 {
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "scc", "memory");
 }
 // lane masks of a < b (signed; the bound is a scalar, or a vector with `vbound`)
 __device__ __forceinline__ unsigned long long mask_lt_i32(uint32_t a, int b, bool vbound = false)
@@ -181,17 +181,17 @@ __device__ __forceinline__ unsigned long long mask_th_hi(int th, uint32_t m)
 __device__ __forceinline__ void masked_lds_write_b8(unsigned long long mask, uint32_t addr, uint32_t v)
 {
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "scc", "memory");
 }
 __device__ __forceinline__ void masked_lds_write_b8_hi(unsigned long long mask, uint32_t addr, uint32_t v)  // bits 23..16 of v
 {
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8_d16_hi %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8_d16_hi %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "scc", "memory");
 }
 __device__ __forceinline__ void masked_lds_write_b16(unsigned long long mask, uint32_t addr, uint32_t v)
 {
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "scc", "memory");
 }
 // LDS add without a return value, issued by the calling lane(s) as written
 __device__ __forceinline__ void lds_add(uint32_t* addr, uint32_t v)

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
         const uint32_t* ytab = tabs + D.ytabOff;
         const int strips = (dh + R - 1) / R, chunks = (dw + 255) / 256;
         // source level through a buffer descriptor: rows 0..sh-1, the last one up to its 4-byte-rounded end (the aligned
-        // level-0 contract, orbfe.h); a dword past that reads 0 and can only hold bytes no output uses
+        // level-0 contract, orbfe.h); lanes whose dword would start past a row's rounded width use kNowhere (below), so
+        // the descriptor's range check is only the mechanism that drops those lanes, never the guard of the frame's end
         const __amdgpu_buffer_rsrc_t srsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (sh - 1) * spitch + ((sw + 3) & ~3), 0x00020000);
         const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dh * dpitch, 0x00020000);
@@ -255,8 +256,14 @@ __global__ __launch_bounds__(kPyrWaves * 64) void pyramid_kernel(const PipelineD
             // second dword (and, for the stores, lanes past the level width) use a byte offset beyond the buffer -- the
             // range check drops the access -- instead of an EXEC mask and a branch around every load and store.
             constexpr uint32_t kNowhere = 0x7ffffff0u;
-            const uint32_t ldA = segBase + 4u * (uint32_t)lane;  // the lane's two dwords of a staged row
-            const uint32_t ldB = lane < kPyrSegDw - 64 ? ldA + 256u : kNowhere;
+            // the lane's two dwords of a staged row.  The row offset travels in the instruction's SGPR offset, which the
+            // buffer range check may not see (only the per-lane offset is guaranteed to be tested), so a dword that would
+            // start past the row's 4-byte-rounded width is sent nowhere HERE: with the row clamped to sh - 1 every load
+            // then ends inside pitch * (sh - 1) + round4(sw), the input contract of orbfe.h, whatever the descriptor does
+            const uint32_t rowEnd = (uint32_t)((sw + 3) & ~3);
+            const uint32_t colA = segBase + 4u * (uint32_t)lane;
+            const uint32_t ldA = colA + 4u <= rowEnd ? colA : kNowhere;
+            const uint32_t ldB = (lane < kPyrSegDw - 64 && colA + 260u <= rowEnd) ? colA + 256u : kNowhere;
             const uint32_t stX = colOk ? (uint32_t)x0 : kNowhere;
             const bool partial = (dw & 3) != 0;  // the level's last column group is narrower than a dword (wave-uniform)
 

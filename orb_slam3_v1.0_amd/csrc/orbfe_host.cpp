@@ -503,6 +503,10 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
     // frame extent the kernels read (orbfe.h, input contract): whole dwords on the aligned path
     const size_t rowEnd = aligned4 ? (size_t)((h->prm.image_width + 3) & ~3) : (size_t)h->prm.image_width;
     if (batch > 1 && frame_stride < (size_t)pitch * (h->prm.image_height - 1) + rowEnd) return ORBFE_ERR_INVALID_ARG;
+    // the kernels address a frame with 32-bit byte offsets and send dropped lanes to offset 0x7ffffff0 of a buffer
+    // descriptor: a frame must end below that (480 rows at an 8 MiB pitch would wrap the row offsets)
+    if ((size_t)pitch * (h->prm.image_height - 1) + (size_t)((h->prm.image_width + 3) & ~3) >= (size_t)0x7ffffff0u)
+        return ORBFE_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
     // while the chain is being captured into a hipGraph the hand-over events stay outside it: the replay path waits

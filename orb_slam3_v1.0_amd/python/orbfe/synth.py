@@ -85,3 +85,107 @@ def pink_stream(w, h, count, index0=0):
         yield _noise(big[oy:oy + h, ox:ox + w], rng)
         ox = min(max(ox + int(rng.integers(-4, 5)), 0), 2 * pad)
         oy = min(max(oy + int(rng.integers(-4, 5)), 0), 2 * pad)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Hostile image classes ("parity on hostile inputs"): content the rectangle / disc generator never makes and
+# on which the reference's FAST / NMS edge cases are decided (src/cuda/Fast_gpu.cu:193-216 score saturation, :222-267
+# threshold boundaries, :289-319 strict-> ties), plus maximum corner density for the queues, caps and node tables.
+# Every class is a pure function of (kind, w, h, seed).
+# --------------------------------------------------------------------------------------------------------------------
+HOSTILE_KINDS = ("noise", "checker1", "checker2", "checker3", "checker4", "plateau", "extreme", "seams", "thresh",
+                 "pink", "lowtex", "saltpepper")
+
+
+def _stamp(img, x, y, bw, bh, g):
+    h, w = img.shape
+    img[max(0, y):min(h, y + bh), max(0, x):min(w, x + bw)] = g
+
+
+def hostile(kind, w, h, seed=0, tile=(64, 32)):
+    """One u8 frame of the named hostile class."""
+    rng = np.random.default_rng(SEED0 + 15485863 * (seed + 1) + sum(map(ord, kind)))
+    if kind == "noise":  # uniform white noise: maximum corner density at every level
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind.startswith("checker"):  # period 1..4; full contrast on the left half, contrast 24 (> iniTh) on the right
+        p = int(kind[7:])
+        yy, xx = np.mgrid[0:h, 0:w]
+        on = ((xx // p + yy // p) & 1).astype(bool)
+        img = np.where(on, 255, 0)
+        soft = np.where(on, 140, 116)
+        img[:, w // 2:] = soft[:, w // 2:]
+        return img.astype(np.uint8)
+    if kind == "plateau":
+        # lattice of IDENTICAL blobs (1x1, 2x1, 1x2, 2x2, 3x3, 3x2 in rotation) on a flat background: all pixels of a
+        # blob score the same, so strict > lets neighbours suppress each other (Fast_gpu.cu:300-310); the blob grey
+        # flips polarity per lattice row; pitch 7 x 6 px so blobs drift across every tile and level phase
+        bg, shapes = 90, ((1, 1), (2, 1), (1, 2), (2, 2), (3, 3), (3, 2))
+        img = np.full((h, w), bg, np.int32)
+        k = 0
+        for j, y in enumerate(range(2, h - 3, 6)):
+            g = 200 if j & 1 else 20
+            for x in range(2, w - 3, 7):
+                bw, bh = shapes[k % len(shapes)]
+                _stamp(img, x, y, bw, bh, g)
+                k += 1
+        return img.astype(np.uint8)
+    if kind == "extreme":
+        # all-0 top half with isolated 255 pixels, all-255 bottom half with isolated 0 pixels (score 254, the largest
+        # the binary search of :193-216 can return), and 2-px pairs of them (equal maximal scores side by side)
+        img = np.zeros((h, w), np.int32)
+        img[h // 2:] = 255
+        n = max(8, w * h // 400)
+        xs, ys = rng.integers(0, w, n), rng.integers(0, h, n)
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            v = 255 if y < h // 2 else 0
+            img[y, x] = v
+            if i % 3 == 0 and x + 1 < w:
+                img[y, x + 1] = v
+        return img.astype(np.uint8)
+    if kind == "seams":
+        # rectangle corners and step edges ON the FAST tile seams (multiples of tile w / h and the pixels either side)
+        # and on the tested-region border (x, y in {5, 6, w-6, w-5}); grey levels alternate so that both polarities occur
+        tw, th_ = tile
+        img = np.full((h, w), 128, np.int32)
+        k = 0
+        for y0 in list(range(0, h, th_)) + [5, 6, h - 6, h - 5]:
+            for x0 in list(range(0, w, tw)) + [5, 6, w - 6, w - 5]:
+                dx, dy = (k % 3) - 1, ((k // 3) % 3) - 1  # corner at the seam or one pixel either side
+                g = (30, 220, 70, 180)[k % 4]
+                _stamp(img, x0 + dx, y0 + dy, 9 + k % 5, 7 + k % 4, g)
+                k += 1
+        # isolated single pixels exactly at the first / last tested coordinates of level 0
+        for (x, y) in ((6, 6), (w - 6, 6), (6, h - 6), (w - 6, h - 6), (5, 5), (w - 5, h - 5), (6, h // 2), (w // 2, h - 6)):
+            img[y, x] = 255
+        return img.astype(np.uint8)
+    if kind == "thresh":
+        # blobs whose contrast is exactly th and th + 1 for the usual thresholds (7, 20) and near saturation: the
+        # compare is strict (`> th`), and v + th passes 255 for bright centres
+        img = np.full((h, w), 100, np.int32)
+        img[:, 2 * w // 3:] = 245  # bright background: v + th > 255
+        img[: h // 4, : w // 3] = 8  # dark background: v - th < 0
+        deltas = (7, 8, -7, -8, 20, 21, -20, -21, 6, -6, 9, -9, 19, -19, 10, -10)
+        k = 0
+        for y in range(3, h - 4, 9):
+            for x in range(3, w - 4, 9):
+                d = deltas[k % len(deltas)]
+                s = 1 + (k // len(deltas)) % 3
+                base = int(img[y, x])
+                _stamp(img, x, y, s, s, min(255, max(0, base + d)))
+                k += 1
+        return img.astype(np.uint8)
+    if kind == "pink":
+        return _noise(_pink(w, h, rng), rng)
+    if kind == "lowtex":  # bench.py --texture-sweep's low-texture density
+        return _noise(_base(w, h, rng, 0.0002), rng)
+    if kind == "saltpepper":  # flat grey with 2 % salt and 2 % pepper: isolated maximal corners of both polarities
+        img = np.full((h, w), 128, np.uint8)
+        r = rng.random((h, w))
+        img[r < 0.02] = 0
+        img[r > 0.98] = 255
+        return img
+    raise ValueError(kind)
+
+
+def lowtex_stream(w, h, count, index0=0):
+    return stream(w, h, count, index0=index0, density=0.0002)

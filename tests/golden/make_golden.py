@@ -5,7 +5,7 @@ The reference has no tests or golden data and cannot be bu
 pin the ORACLE's output on small seeded inputs: the non-GPU suite checks the oracle still reproduces
 them (guards against silent spec drift), the GPU suite checks the HIP path against them.
 Inputs are stored in the fixture, so the check does not depend on the synthetic generator.
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py   (writes the fixtures that do not exist yet; --all rewrites all)
 """
 import os
 import sys
@@ -25,6 +25,11 @@ CASES = {
     "g160x120_l4": (200, 8000, 1.2, 4, 20, 7, 160, 120, 21),
     "g201x97_l3_s15": (120, 6000, 1.5, 3, 25, 9, 201, 97, 22),
     "g96x96_l1_cap": (60, 150, 1.2, 1, 20, 7, 96, 96, 23),  # nFast small: exercises the caps (S2b)
+    # hostile classes (orbfe.synth.hostile; a 10th entry names the class): white noise with both caps active, a lattice of
+    # equal-score blobs (strict-> NMS ties), a period-3 checkerboard over a tile seam
+    "g144x100_l3_noise": (150, 600, 1.2, 3, 20, 7, 144, 100, 24, "noise"),
+    "g136x72_l2_plateau": (120, 6000, 1.2, 2, 20, 7, 136, 72, 25, "plateau"),
+    "g130x70_l3_checker3": (100, 5000, 1.25, 3, 20, 7, 130, 70, 26, "checker3"),
 }
 NAMES = ("projX", "projY", "viewCos", "trackDepth", "level", "inView", "bad", "observations")
 
@@ -32,7 +37,9 @@ NAMES = ("projX", "projY", "viewCos", "trackDepth", "level", "inView", "bad", "o
 def main():
     for name, c in CASES.items():
         args, idx = c[:8], c[8]
-        img = synth.frame(args[6], args[7], idx)
+        if os.path.exists(os.path.join(HERE, name + ".npz")) and "--all" not in sys.argv:
+            continue  # committed fixtures are data: they are only rewritten on request
+        img = synth.frame(args[6], args[7], idx) if len(c) == 9 else synth.hostile(c[9], args[6], args[7], idx)
         e = O.Extractor(*args)
         kp, desc, per = e.extract(img)
         out = dict(args=np.array(args, np.float64), image=img, kp=kp, desc=desc, per_level=per,

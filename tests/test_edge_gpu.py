@@ -115,6 +115,46 @@ def test_extract_rejects_bad_arguments(built):
     assert L.orbfe_get_pyramid_level(ex.h, 0, 99, 0, kp.ctypes.data, 320) == 1
 
 
+def test_last_frame_flush_with_the_end_of_its_buffer(built):
+    """the pyramid kernel's row offset travels in the buffer instruction's scalar offset, which the range check
+    need not see -- its lanes are bounded by the row width instead.  A tight [B][H][W] device buffer of EXACTLY the
+    contract size (pitch * (H - 1) + round4(W) for the last frame, W * H = 225 pages at 1280x720) gives the oracle's
+    results for the last frame, and a device pitch past the 32-bit frame extent is refused."""
+    import torch
+    import orbfe
+    args = (500, 40000, 1.2, 8, 20, 7, 1280, 720)
+    W, H, B = 1280, 720, 2
+    ex = orbfe.ORBextractor(*args, device=0, max_batch=B)
+    ref = O.Extractor(*args)
+    ims = [synth.frame(W, H, 70 + b) for b in range(B)]
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(np.stack(ims).reshape(-1)).to(dev)  # numel == B * W * H: nothing of ours behind the last row
+    assert d_in.numel() == B * W * H
+    cap = ex.cap
+    d_kp = torch.zeros(B * cap * 24, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_in.data_ptr(), W * H, W, B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), None, None)
+    torch.cuda.synchronize(dev)
+    n = d_n.cpu().numpy()
+    kp = d_kp.cpu().numpy().view(orbfe.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+    for b in range(B):
+        kp_r, desc_r, _ = ref.extract(ims[b])
+        assert n[b] == len(kp_r) and kp[b, :n[b]].tobytes() == kp_r.tobytes() and np.array_equal(desc[b, :n[b]], desc_r)
+    for l in range(1, 8):
+        assert np.array_equal(ex.pyramid_level(l, False, frame=B - 1), O_level(ref, ims[B - 1], l)), l
+    # 32-bit frame extent: 720 rows at a 4 MiB pitch end past 0x7ffffff0 -> refused before any launch
+    with pytest.raises(orbfe.OrbfeError) as e:
+        ex.extract_batch_device(d_in.data_ptr(), 0, 4 << 20, 1, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), None, None)
+    assert e.value.code == 1
+
+
+def O_level(ref, img, l):
+    ref.extract(img)
+    return ref.level_image(l, False)
+
+
 @pytest.mark.gpu
 def test_graph_replay_equals_plain_launches(built):
     """The host-pointer extract call is replayed as a captured hipGraph; with stage timing on it takes the plain-launch

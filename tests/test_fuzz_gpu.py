@@ -1,5 +1,5 @@
-"""Randomised parity sweep (tests/tools/fuzz_extract.py): random image sizes, pyramid depths, scale factors, thresholds and
-budgets; the GPU extractor must equal the oracle bit for bit or refuse the configuration with the documented
+"""Randomised parity sweep (tests/tools/fuzz_extract.py): random image sizes, pyramid depths, scale factors, thresholds,
+budgets and image classes (the default scene or a hostile class of orbfe.synth); the GPU extractor must equal the oracle bit for bit or refuse the configuration with the documented
 ORBFE_ERR_UNSUPPORTED (portrait images with round(W/H) == 0: the reference divides by zero there)."""
 import os
 import sys
@@ -16,15 +16,18 @@ def test_random_configurations_bit_exact(built):
     import orbfe
     rng = np.random.default_rng(2)
     done = refused = 0
-    for k in range(24):
+    kinds = set()
+    for k in range(32):
         cfg = FZ.random_config(rng)
+        kind = FZ.random_kind(rng)
         try:
-            FZ.check(cfg, seed=100 + k)
+            FZ.check(cfg, seed=100 + k, kind=kind)
             done += 1
+            kinds.add(kind)
         except orbfe.OrbfeError as err:
             assert err.code == 2 and round(cfg[6] / cfg[7]) == 0, (cfg, str(err))
             refused += 1
-    assert done >= 15
+    assert done >= 20 and len(kinds) >= 5
 
 
 @pytest.mark.gpu

@@ -153,6 +153,31 @@ def test_fast_detect_semantics():
                     assert False, "adjacent survivors"
 
 
+@pytest.mark.parametrize("kind", synth.HOSTILE_KINDS)
+def test_fast_detect_on_hostile_classes_equals_python_restatement(kind):
+    """The oracle's detect() against the independent Python restatement above on the hostile image classes (white noise,
+    checkerboards, lattices of equal-score blobs, saturated frames, contrasts of exactly th / th + 1, seams): pins the
+    strict-> tie rule (Fast_gpu.cu:300-310), the saturated scores (:193-216) and the threshold boundary (:60-65) of the
+    ORACLE, which the GPU parity tests of tests/test_hostile_gpu.py then carry over to the HIP path."""
+    W, H = 80, 56
+    img = synth.hostile(kind, W, H, 1, tile=(32, 16))
+    for th in (7, 20):
+        score = np.zeros((H, W), np.int32)
+        for y in range(6, H - 5):
+            for x in range(6, W - 5):
+                score[y, x] = py_score(img, x, y, th)
+        pad = np.pad(score, 1)
+        nb = np.stack([pad[1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if dx or dy])
+        keep = (score > 0) & (score > nb.max(axis=0))
+        ys, xs = np.nonzero(keep)  # raster order
+        xy, resp, pre = O.fast_detect(img, th, 1 << 20)
+        assert pre == int((score > 0).sum()), (kind, th)
+        assert np.array_equal(xy[:, 0], xs) and np.array_equal(xy[:, 1], ys), (kind, th)
+        assert np.array_equal(resp, score[ys, xs]), (kind, th)
+    if kind in ("extreme", "saltpepper"):
+        assert resp.max() >= 126  # isolated extreme pixels: 254 on the saturated frame, 127 on mid-grey
+
+
 # ------------------------------------------------------------------ quadtree: second, independent restatement
 def py_distribute(xy, resp, W, H, N):
     """Literal std::list choreography of src/ORBextractor.cc:226-431 on Python lists (S4 order)."""

@@ -1,6 +1,8 @@
 """BASELINE configs C2/C3, C4 and C5 at stream length: every frame of a synthetic stream (256 x 752x480, 64 x 1280x720,
 64 x 1024x1024 with 12 levels) is extracted on the GPU (batched) and compared bit for bit with the CPU oracle; a quarter of
-the frames also go through SearchByProjection."""
+the frames also go through SearchByProjection.  The two extra streams `bench.py --texture-sweep` times -- 1/f ("pink")
+noise, which doubles the FAST candidate population, and the low-texture scene -- run at the headline geometry too, so
+every number the bench prints is on a verified workload."""
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -8,7 +10,10 @@ import pytest
 
 import oracle_py as O
 
-CASES = {"euroc_752x480": 256, "batched_1280x720": 64, "tumvi_1024x1024": 64}  # bench.WORKLOADS name -> frames
+# case -> (bench.WORKLOADS name, synth stream generator, frames)
+CASES = {"euroc_752x480": ("euroc_752x480", "stream", 256), "batched_1280x720": ("batched_1280x720", "stream", 64),
+         "tumvi_1024x1024": ("tumvi_1024x1024", "stream", 64),
+         "euroc_752x480_pink": ("euroc_752x480", "pink_stream", 128), "euroc_752x480_lowtex": ("euroc_752x480", "lowtex_stream", 128)}
 
 
 @pytest.mark.gpu
@@ -17,9 +22,10 @@ def test_stream_bit_exact(built, name):
     import bench
     import orbfe
     from orbfe import synth
-    ARGS, n_frames = tuple(bench.WORKLOADS[name]), CASES[name]
+    workload, gen, n_frames = CASES[name]
+    ARGS = tuple(bench.WORKLOADS[workload])
     W, H = ARGS[6], ARGS[7]
-    frames = list(synth.stream(W, H, n_frames, index0=1000))
+    frames = list(getattr(synth, gen)(W, H, n_frames, index0=1000))
     ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=64)
     gpu = []
     for i in range(0, len(frames), 64):
