@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the MI355X ORB front-end (BASELINE.json metric).
 
-A "step" is one pass of the hot path -- ORB extraction of a batch of synthetic frames that are already resident in
-HBM, followed by SearchByProjection of 2000 map points per frame against the fresh keypoints (SURVEY.md section 8d,
-config C3 recipe).  One process per GPU; for N > 1 launch with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE
-from the env).  Two multi-GPU modes (`config.workload` names the one that ran):
-  weak    every rank brings its own --batch frames (default for the 752x480 headline workload);
+A "step" is one pass of the hot path -- ORB extraction of a batch of frames that are already resident in HBM, followed
+by SearchByProjection of 2000 map points per frame against the fresh keypoints (SURVEY.md section 8d, config C3 recipe).
+One process per GPU.  `python bench.py --gpus N` is self-contained: with N > 1 and no WORLD_SIZE in the environment the
+parent -- before it touches the GPU -- starts N ranks through torch.distributed.run on 127.0.0.1 and relays rank 0's
+JSON line; under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the env) it is one of those ranks.
+`n_gpus` is the size of the RCCL group that actually ran, and a mismatch with --gpus is an error.
+Two multi-GPU modes (`config.workload` names the one that ran):
+  weak    every rank brings its own --batch frames (default for the 752x480 headline workload); per step the ranks
+          exchange only the per-frame keypoint / match COUNTS (8 B per frame) -- results stay on the GPU that made them;
   strong  BASELINE config 4: --workload batched_1280x720 is 512 frames IN TOTAL, rank r owns shard_range(512, r, N)
-          (64 per GPU at N = 8) -- `value` is still total frames / time.
-Either way there is no data-path collective; the per-step results are gathered with one RCCL all_gather (the "trivial
-descriptor gather" of BASELINE.json config 4).
+          (64 per GPU at N = 8) and the padded results (keypoints + descriptors + match indices, 60 B per slot) are
+          all-gathered once per step -- the "trivial descriptor gather" of BASELINE.json config 4.  `value` is still
+          total frames / time.  --emulate-world K runs rank 0's shard of a K-rank split on ONE GPU (no collective).
+There is no data-path collective; `config.gather_bytes_per_step` says what each GPU receives per step.
 
 Prints ONE JSON line on rank 0 (driver contract), including
   roofline      dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s, plus the instruction
                 side (`issue`) and the PMC traffic of the committed profile of the SAME sources (`profiles_head`)
   cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) pinned to one host core
+  latency       the reference's own call shape -- ONE host frame per call (src/Frame.cc:178-189): orbfe_extract from
+                pageable and pinned memory, orbfe_match_projection (2000 map points), orbfe_prepare_and_extract, each
+                the median of >= 200 calls, next to the single-thread oracle on the same call
   value_host_io frames/s with host pointers in and out through the pipelined ring (orbfe_stream_*)
   matcher       map points/s and brute-force-equivalent Hamming pairs/s of the SearchByProjection stage.
+--images DIR runs the same step on grey-converted image files (PGM / PNG / JPEG via PIL, centre-cropped or resized to
+the workload geometry) for BASELINE configs 2/3/5 where EuRoC / TUM-VI data exists; the default is synthetic.
 """
 import argparse
 import contextlib
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -193,7 +205,7 @@ class StepRunner:
     def __init__(self, device, B, cap, n_levels, extract_fn, match_fn, dist=None, world=1, gather=False, overlap=True,
                  frame_sets=1):
         self.dev, self.B, self.cap, self.world = device, B, cap, world
-        self.extract_fn, self.match_fn, self.dist, self.gather = extract_fn, match_fn, dist, gather
+        self.extract_fn, self.match_fn, self.dist = extract_fn, match_fn, dist
         self.frame_sets = frame_sets
         self.cuda = device.type == "cuda"
         self.nbuf = 2 if (match_fn is not None and overlap and self.cuda) else 1
@@ -207,10 +219,16 @@ class StepRunner:
                                   nmatch=torch.zeros(B, dtype=torch.int32, device=device),
                                   ev_ext=torch.cuda.Event() if self.cuda else None,
                                   ev_done=torch.cuda.Event() if self.cuda else None))
-        if gather:
+        # gather: False / "none", "counts" (per-frame keypoint + match counts only) or True / "full" (padded results)
+        self.gather = {True: "full", False: "none", None: "none"}.get(gather, gather)
+        assert self.gather in ("none", "counts", "full")
+        if self.gather == "full":
             self.pack = torch.zeros((B, cap, SLOT_BYTES), dtype=torch.uint8, device=device)
             self.g_out = torch.zeros((world * B, cap, SLOT_BYTES), dtype=torch.uint8, device=device)  # rank-major
             self.g_n = torch.zeros(world * B, dtype=torch.int32, device=device)
+        elif self.gather == "counts":
+            self.cnt = torch.zeros((B, 2), dtype=torch.int32, device=device)
+            self.g_cnt = torch.zeros((world * B, 2), dtype=torch.int32, device=device)  # rank-major: (keypoints, matches)
         self.s1 = self.s2 = None
         if self.cuda:
             self.s1 = torch.cuda.current_stream(device)
@@ -239,16 +257,27 @@ class StepRunner:
             if timed and self.cuda:
                 e1.record(self.s2)
                 self.match_events.append((e0, e1))
-        if self.gather:
+        if self.gather == "full":
             with self._on(self.s2):
                 self.pack[:, :, :24] = b["kp"]
                 self.pack[:, :, 24:56] = b["desc"]
                 self.pack[:, :, 56:] = b["match"].view(torch.uint8).reshape(self.B, self.cap, 4)
                 self.dist.all_gather_into_tensor(self.g_out, self.pack)
                 self.dist.all_gather_into_tensor(self.g_n, b["n"])
+        elif self.gather == "counts":
+            with self._on(self.s2):
+                self.cnt[:, 0] = b["n"]
+                self.cnt[:, 1] = b["nmatch"]
+                self.dist.all_gather_into_tensor(self.g_cnt, self.cnt)
         if self.nbuf == 2:
             b["ev_done"].record(self.s2)
         return b
+
+    def gather_bytes_per_step(self):
+        """bytes every GPU RECEIVES per step through the collective"""
+        if self.gather == "full":
+            return self.world * self.B * (self.cap * SLOT_BYTES + 4)
+        return self.world * self.B * 8 if self.gather == "counts" else 0
 
     def match_ms(self):
         return sum(e0.elapsed_time(e1) for e0, e1 in self.match_events) / max(1, len(self.match_events))
@@ -284,6 +313,172 @@ def host_io_rate(ex, frames, slot_frames, rounds, pinned):
     return done / dt
 
 
+def _free_port():
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started as ONE process: start N ranks (one per GPU) through torch.distributed.run on
+    127.0.0.1 and relay rank 0's JSON line.  The parent never initialises the GPU (no torch.cuda call, no HIP call): the
+    ranks are fresh child processes.  Returns the exit code of the launch."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL (the host driver supports nothing else)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(out)  # anything else the ranks print is not the result line
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank launch failed with exit code %d\n" % (n, rc))
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the %d-rank launch printed no result line\n" % n)
+        return 3
+    print(line, flush=True)
+    return 0
+
+
+def load_image_dir(path, W, H, count):
+    """--images DIR: grey frames of the workload geometry from image files (sorted by name; PGM / PNG / JPEG / BMP / TIFF
+    via PIL).  A larger image is centre-cropped when it is at most 1.25x the geometry (EuRoC 752x480, TUM-VI 512x512 /
+    1024x1024 frames fit as they are), otherwise resized with its aspect ratio kept and then centre-cropped; a smaller
+    one is resized up.  The list is repeated to `count` frames.  Returns ([count][H][W] u8, number of files read)."""
+    from PIL import Image
+    names = sorted(f for f in os.listdir(path) if f.lower().endswith((".pgm", ".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff")))
+    if not names:
+        raise SystemExit("--images %s: no image files" % path)
+    frames = []
+    for f in names[:count]:
+        im = Image.open(os.path.join(path, f)).convert("L")
+        w, h = im.size
+        if not (W <= w <= 1.25 * W and H <= h <= 1.25 * H):
+            k = max(W / w, H / h)
+            im = im.resize((max(W, int(round(w * k))), max(H, int(round(h * k)))), Image.BILINEAR)
+            w, h = im.size
+        x0, y0 = (w - W) // 2, (h - H) // 2
+        frames.append(np.asarray(im.crop((x0, y0, x0 + W, y0 + H)), np.uint8))
+    n_files = len(frames)
+    while len(frames) < count:
+        frames.append(frames[len(frames) % n_files])
+    return np.stack(frames), n_files
+
+
+def _median_ms(fn, reps, warm=5):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t)
+    return float(np.median(ts)) * 1e3
+
+
+def latency_block(cfg, device_index, frames, reps=200):
+    """The reference's call shape: ONE host image per call (src/Frame.cc:178-189: ExtractORB on the frame the node hands
+    over at 20 Hz, ros2_ws/src/mono-inertial/src/mono_inertial_node.cpp:207), then one SearchByProjection
+    (src/Tracking.cc:1115), and the node-side preparation + extraction chain (image_grabber.hpp:96-110).  Wall time per
+    call through the C ABI (upload, kernels, download, synchronisation), median of `reps` calls, and the single-thread
+    oracle's median on the same call."""
+    import orbfe
+    import oracle_py as O
+    from orbfe import synth
+    W, H = cfg[6], cfg[7]
+    ex1 = orbfe.ORBextractor(*cfg, device=device_index, max_batch=1)
+    m1 = orbfe.ORBmatcher(ex1)
+    ref = O.Extractor(*cfg)
+    pageable = [np.ascontiguousarray(f) for f in frames[:32]]
+    pinned = [torch.from_numpy(f.copy()).pin_memory().numpy() for f in pageable]
+    for f in pinned:  # the first DMA access to a fresh pinned allocation maps it
+        ex1.extractFeatures(f)
+    it = {"i": 0}
+
+    def call_extract(src):
+        def fn():
+            it["i"] += 1
+            return ex1.extractFeatures(src[it["i"] % len(src)])
+        return fn
+
+    out = {"unit": "ms per call, median of %d" % reps, "calls": reps}
+    out["extract_pageable_ms"] = _median_ms(call_extract(pageable), reps)
+    out["extract_pinned_ms"] = _median_ms(call_extract(pinned), reps)
+    out["extract_oracle_ms"] = _median_ms(lambda: ref.extract(pageable[0]), 15, 2)
+    kp, desc = ex1.extractFeatures(pageable[0])
+    rng = np.random.default_rng(11)
+    mps, mpd = make_map_points(kp, len(kp), desc, N_MAP_POINTS, rng, ex1.nlevels, orbfe.MP_DTYPE)
+    fv = orbfe.make_frame_view(kp, desc, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ex1.mvScaleFactor)
+    out["match_projection_ms"] = _median_ms(lambda: m1.SearchByProjection(fv, mps, mpd, MATCH_TH, False, 0.0, MATCH_NN, None), reps)
+    kp_r, desc_r, _ = ref.extract(pageable[0])
+    fvo = O.make_frame_view(kp_r, desc_r, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors)
+    out["match_projection_oracle_ms"] = _median_ms(lambda: O.search_by_projection(fvo, mps.view(O.MP_DTYPE), mpd, None, MATCH_TH, MATCH_NN), 15, 2)
+    out["match_projection_map_points"] = N_MAP_POINTS
+    # node-side chain at the node's own configuration (mono_inertial_node.cpp:20,59-71): 2048x1536 BGR -> 614x460 grey -> extract
+    SW, SH, DW, DH = 2048, 1536, 614, 460
+    pcfg = (cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], DW, DH)
+    exp = orbfe.ORBextractor(*pcfg, device=device_index, max_batch=1)
+    bgr = synth.colour_image(SW, SH, 1)
+    map1, map2 = synth.fisheye_maps(SW, SH, 1)
+    prep = orbfe.ImagePreparer(exp, map1, map2, DW, DH)
+    bgr_pinned = torch.from_numpy(bgr.copy()).pin_memory().numpy()
+    out["prepare_and_extract_pinned_ms"] = _median_ms(lambda: prep.extract(bgr_pinned), reps)
+    out["prepare_and_extract_pageable_ms"] = _median_ms(lambda: prep.extract(bgr), max(20, reps // 4))
+    refp = O.Extractor(*pcfg)
+
+    def oracle_chain():
+        refp.extract(O.prepare_image(bgr, map1, map2, DW, DH))
+    out["prepare_and_extract_oracle_ms"] = _median_ms(oracle_chain, 3, 1)
+    out["what"] = ("one %dx%d host frame per call through orbfe_extract (one captured hipGraph: H2D, kernels, D2H, sync); "
+                   "orbfe_match_projection with %d map points, host pointers; orbfe_prepare_and_extract %dx%d BGR -> %dx%d; "
+                   "`*_oracle_ms` = the single-thread C oracle on the same call" % (W, H, N_MAP_POINTS, SW, SH, DW, DH))
+    prep.close()
+    return out
+
+
+def launcher_selftest(a, rank, world):
+    """--selftest-launcher (tests/test_distributed_cpu.py): the rank bookkeeping of this script -- launch, process group,
+    StepRunner buffer rotation, the per-step collective, the MAX-over-ranks timing and rank 0's JSON line -- on CPU tensors
+    over gloo with a stub in place of the HIP calls.  It measures nothing: metric "selftest", value 0."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, cap, nl = 3, 5, 2
+
+    def extract_fn(b, fs):
+        for j in range(B):
+            b["n"][j] = rank * B + j + 1
+
+    def match_fn(b, fs):
+        for j in range(B):
+            b["nmatch"][j] = rank + j
+
+    mode = "none" if a.no_gather else (a.gather if a.gather != "auto" else "counts")
+    r = StepRunner(torch.device("cpu"), B, cap, nl, extract_fn, match_fn, dist, world, mode, True, 1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r.step()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if dist.get_world_size() != a.gpus:
+        raise SystemExit("selftest: --gpus %d but the process group has %d ranks" % (a.gpus, dist.get_world_size()))
+    if rank == 0:
+        counts = r.g_cnt.view(world, B, 2).tolist() if mode == "counts" else None
+        print(json.dumps({"metric": "selftest", "value": 0.0, "unit": "none", "n_gpus": dist.get_world_size(), "steps": a.steps,
+                          "warmup": a.warmup, "data": "stub", "config": {"workload": "launcher self-test (no device work)",
+                                                                          "gather": mode, "gather_bytes_per_step": r.gather_bytes_per_step()},
+                          "gathered_counts": counts}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,19 +496,40 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-io", action="store_true", help="skip the host-pointer ring measurement (value_host_io)")
     ap.add_argument("--texture-sweep", action="store_true", help="also time a low-texture and a 1/f-noise stream")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", default="auto", choices=["auto", "full", "counts", "none"],
+                    help="per-step RCCL collective at N > 1.  auto: `full` (all_gather of the padded keypoints + descriptors + "
+                         "match indices, BASELINE config 4) in strong mode, `counts` (8 B per frame) in weak mode")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--force-gather", action="store_true",
-                    help="run the RCCL result gather even at N=1 (a 1-rank process group): exercises the N>1 code path on one GPU")
+                    help="run the per-step collective even at N=1 (a 1-rank process group): exercises the N>1 code path on one GPU")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="K",
+                    help="strong mode on ONE GPU: run rank 0's shard of a K-rank split (512 / K frames per step), no collective; "
+                         "predicts the per-GPU step time of the K-GPU run")
+    ap.add_argument("--images", default=None, metavar="DIR",
+                    help="grey-convert the image files of DIR (sorted; PGM / PNG / JPEG via PIL, centre-cropped or resized to the "
+                         "workload geometry) instead of the synthetic stream")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency block")
+    ap.add_argument("--latency-calls", type=int, default=200)
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-match", action="store_true", help="extract only")
     ap.add_argument("--no-overlap", action="store_true", help="match on the extraction stream (no 2-stream pipelining)")
     ap.add_argument("--lib", default=None, help="load this build of liborbfe instead (tools/: the timing-only ablation build)")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as one process: become the launcher of N ranks BEFORE anything touches the GPU
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.selftest_launcher:
+        return launcher_selftest(a, rank, world)
+    if a.emulate_world and (world > 1 or a.emulate_world < 1):
+        raise SystemExit("--emulate-world K needs K >= 1 and a single-GPU run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -328,6 +544,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != a.gpus:  # n_gpus of the result line is the group that ran, never the flag
+            raise SystemExit("--gpus %d but the RCCL group has %d ranks" % (a.gpus, dist.get_world_size()))
+        world = dist.get_world_size()
 
     import orbfe
     from orbfe import synth
@@ -338,14 +557,18 @@ def main():
     cfg = WORKLOADS[a.workload]
     W, H = cfg[6], cfg[7]
     scaling = a.scaling if a.scaling != "auto" else ("strong" if a.workload == "batched_1280x720" else "weak")
+    emu = a.emulate_world if scaling == "strong" else 0
+    if a.emulate_world and not emu:
+        raise SystemExit("--emulate-world applies to strong scaling (--workload batched_1280x720 or --scaling strong)")
     if scaling == "strong":
-        lo, hi = shard_range(C4_TOTAL_FRAMES, rank, world)
-        B, frame0, frames_total = hi - lo, lo, C4_TOTAL_FRAMES
+        lo, hi = shard_range(C4_TOTAL_FRAMES, rank, emu or world)
+        B, frame0 = hi - lo, lo
+        frames_total = B if emu else C4_TOTAL_FRAMES  # emulation: `value` counts the frames this one GPU really processed
         if B < 1:
             raise SystemExit("more ranks than frames")
     else:
         B, frame0, frames_total = a.batch, rank * a.batch, world * a.batch
-    Bpad = (frames_total + world - 1) // world if scaling == "strong" else B  # gather slots per rank
+    Bpad = (C4_TOTAL_FRAMES + world - 1) // world if (scaling == "strong" and not emu) else B  # gather slots per rank
     M = 0 if a.no_match else N_MAP_POINTS
     ex = orbfe.ORBextractor(*cfg, device=local_rank, max_batch=max(B, Bpad))
     matcher = orbfe.ORBmatcher(ex)
@@ -357,8 +580,16 @@ def main():
         sets = [np.stack(list(stream_fn(W, H, B, 1000 * s + frame0))) for s in range(n_sets)]
         return sets, [torch.from_numpy(f).to(dev) for f in sets]
 
-    frames_sets, d_gray = gen_sets(lambda w, h, n, i0: synth.stream(w, h, n, index0=i0))
-    gather = (world > 1 or a.force_gather) and not a.no_gather
+    n_image_files = 0
+    if a.images:
+        imgs, n_image_files = load_image_dir(a.images, W, H, n_sets * B)
+        frames_sets = [imgs[k * B:(k + 1) * B] for k in range(n_sets)]
+        d_gray = [torch.from_numpy(np.ascontiguousarray(f)).to(dev) for f in frames_sets]
+    else:
+        frames_sets, d_gray = gen_sets(lambda w, h, n, i0: synth.stream(w, h, n, index0=i0))
+    gather = "none"
+    if (world > 1 or a.force_gather) and not a.no_gather and not emu:
+        gather = a.gather if a.gather != "auto" else ("full" if scaling == "strong" else "counts")
     state = {"gray": d_gray, "mps": None, "mpd": None}
 
     def extract_fn(b, fs):
@@ -457,7 +688,7 @@ def main():
                 "extract+match" if M else "extract", W, H, cfg[3], cfg[0]),
             "value": frames_total * a.steps / dt,
             "unit": "frames/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if dist is not None else 1,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
@@ -465,16 +696,22 @@ def main():
             "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "%s synthetic stream, %s, %s, frames resident in HBM (%d frame sets in rotation), "
+            "data": "synthetic" if not a.images else "images: %d files of %s, grey, %dx%d" % (n_image_files, a.images, W, H),
+            "config": {"workload": "%s %s, %s, %s, frames resident in HBM (%d frame sets in rotation), "
                                    "nFeatures=%d levels=%d scale=%.1f FAST %d/%d nFast=%d" % (
-                                       a.workload, what,
+                                       a.workload, "image files" if a.images else "synthetic stream", what,
                                        "%d frames/step/GPU (weak scaling)" % B if scaling == "weak" else
+                                       ("rank 0's shard of a %d-rank split of %d frames: %d frames per step on this ONE GPU (strong "
+                                        "scaling emulated, BASELINE config 4)" % (emu, C4_TOTAL_FRAMES, B)) if emu else
                                        "%d frames per step IN TOTAL, %d on this rank (strong scaling, BASELINE config 4)" % (frames_total, B),
                                        n_sets, cfg[0], cfg[3], cfg[2], cfg[4], cfg[5], cfg[1]),
                        "frames_per_step": frames_total, "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": n_kp_mean,
                        "mean_matches_per_frame": n_match_mean,
-                       "gather": "rccl all_gather of kp+desc+match per step" if gather else "none",
+                       "gather": {"full": "rccl all_gather of the padded kp + desc + match slots per step (60 B per slot)",
+                                  "counts": "rccl all_gather of the per-frame keypoint and match counts per step (8 B per frame); "
+                                            "results stay on the GPU that made them",
+                                  "none": "none"}[gather],
+                       "gather_bytes_per_step": runner.gather_bytes_per_step(),
                        "streams": "extract(step i+1) || match(step i), double-buffered outputs" if runner.nbuf == 2 else "single stream"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
@@ -489,6 +726,11 @@ def main():
                          "extract_pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
                          "stage_ms_per_step": stage_avg},
         }
+        if emu:
+            out["emulate_world"] = {"world": emu, "frames_per_step_total": C4_TOTAL_FRAMES,
+                                    "predicted_value_at_world": C4_TOTAL_FRAMES * a.steps / dt,
+                                    "note": "this GPU ran 1/%d of BASELINE config 4 per step; with independent shards and the "
+                                            "(unmeasured) all_gather hidden, %d GPUs finish the 512 frames in this step time" % (emu, emu)}
         if M:
             mm = stage_avg["match_projection"]
             out["matcher"] = {"ms_per_step": mm, "map_points_per_s": B * M / (mm * 1e-3),
@@ -524,6 +766,11 @@ def main():
                                "mean_keypoints_per_frame": float(runner.bufs[0]["n"][:B].float().mean().item()),
                                "fast_ms": st_ms["fast_nms_blur"] / max(1, nc)}
             out["texture_sweep"] = sweep
+        if not a.no_latency and world == 1 and not emu:
+            try:
+                out["latency"] = latency_block(cfg, local_rank, frames_sets[0], a.latency_calls)
+            except orbfe.OrbfeError as e:
+                out["latency"] = {"error": str(e)}
         if not a.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             sample = frames_sets[0][:64]
             fps, n = cpu_baseline(cfg, sample, a.cpu_seconds, bool(M), orbfe.MP_DTYPE, pin_core=0)

@@ -160,3 +160,76 @@ def test_bench_step_runner_gloo_world2():
                 assert match[j, k] == k + 100 * g + fs
         for j in range(hi - lo, Bpad):  # padding slots of the short shard stay empty
             assert g_n[r, j] == 0
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started as ONE process (no WORLD_SIZE) must start two ranks itself,
+    report the size of the group that actually ran, and relay exactly one JSON line.  --selftest-launcher swaps the HIP
+    calls for a stub and RCCL for gloo; everything else (launch, StepRunner, the default weak-mode collective = per-frame
+    counts only, MAX-over-ranks timing, rank 0's line) is bench.py's own code."""
+    rc, out, err = _run_bench(["--gpus", "2", "--selftest-launcher", "--steps", "3"])
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 2 and out["steps"] == 3
+    assert out["config"]["gather"] == "counts" and out["config"]["gather_bytes_per_step"] == 2 * 3 * 8
+    # rank-major (keypoints, matches) per frame: rank r frame j -> (3 r + j + 1, r + j)
+    assert out["gathered_counts"] == [[[1, 0], [2, 1], [3, 2]], [[4, 1], [5, 2], [6, 3]]]
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus must equal the size of the launch: a single process told --gpus 3 inside a 2-rank environment exits non-zero
+    instead of silently measuring something else."""
+    rc, out, err = _run_bench(["--gpus", "3", "--selftest-launcher"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and out is None and "WORLD_SIZE=2" in err
+    # and the other way round: under a 2-rank launcher with --gpus 1
+    rc, out, err = _run_bench(["--gpus", "1", "--selftest-launcher"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and out is None
+
+
+def test_gather_volume_per_mode():
+    """What each GPU receives per step: the padded all-gather is world x B x (cap x 60 + 4) bytes -- 252 MB at 8 x 512
+    frames of the headline workload, which is why weak mode exchanges counts only (8 B per frame)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    dev = torch.device("cpu")
+    full = bench.StepRunner(dev, 4, 1024, 8, None, None, None, 8, "full", False, 1)
+    counts = bench.StepRunner(dev, 4, 1024, 8, None, None, None, 8, "counts", False, 1)
+    none = bench.StepRunner(dev, 4, 1024, 8, None, None, None, 8, False, False, 1)
+    assert full.gather_bytes_per_step() == 8 * 4 * (1024 * 60 + 4)
+    assert counts.gather_bytes_per_step() == 8 * 4 * 8 and none.gather_bytes_per_step() == 0
+    assert 8 * 512 * (1024 * 60 + 4) > 250e6  # the volume VERDICT r2 flagged for the old default
+
+
+def test_bench_image_directory_loader(tmp_path):
+    """bench.py --images DIR (BASELINE configs 2/3/5 where EuRoC / TUM-VI data exists): files are read in name order,
+    grey-converted, centre-cropped when they nearly fit (a 752x480 EuRoC frame is taken as it is), resized otherwise, and
+    the list is repeated to the batch size."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from PIL import Image
+    from orbfe import synth
+    a = synth.frame(752, 480, 1)
+    big = synth.frame(1504, 960, 2)                      # twice the geometry: resized
+    wide = synth.frame(800, 500, 3)                      # within 1.25x: centre crop, pixels untouched
+    Image.fromarray(a).save(tmp_path / "0001.pgm")
+    Image.fromarray(big).save(tmp_path / "0002.png")
+    Image.fromarray(np.stack([wide] * 3, 2)).save(tmp_path / "0003.png")  # RGB with equal channels -> the same grey
+    (tmp_path / "notes.txt").write_text("not an image")
+    frames, n = bench.load_image_dir(str(tmp_path), 752, 480, 7)
+    assert n == 3 and frames.shape == (7, 480, 752) and frames.dtype == np.uint8
+    assert np.array_equal(frames[0], a)
+    assert np.array_equal(frames[2], wide[10:490, 24:776])
+    assert np.array_equal(frames[3], frames[0]) and np.array_equal(frames[6], frames[0])
+    assert abs(float(frames[1].mean()) - float(big.mean())) < 2.0

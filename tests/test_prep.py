@@ -11,40 +11,7 @@ import oracle_py as O
 f32 = np.float32
 
 
-def colour_image(w, h, seed):
-    """Smooth colour gradients + blocks + noise (three different channels so a channel swap shows)."""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:h, 0:w]
-    img = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) * 3) % 256], 2).astype(np.int32)
-    for _ in range(max(4, w * h // 4000)):
-        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
-        img[y0:y0 + int(rng.integers(3, 40)), x0:x0 + int(rng.integers(3, 40))] = rng.integers(0, 256, 3)
-    img += rng.integers(-6, 7, img.shape)
-    return np.clip(img, 0, 255).astype(np.uint8)
-
-
-def fisheye_maps(w, h, seed, strength=0.18):
-    """Equidistant-fisheye style maps (what cv::fisheye::initUndistortRectifyMap produces for the node, CV_32F) plus the
-    special entries the operators must survive: exact integer coordinates (5 taps, two of weight 0), points outside the
-    image on every side, NaN and infinities, huge values."""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
-    cx, cy, f = w * 0.498, h * 0.512, 0.65 * w
-    a, b = (xx - cx) / f, (yy - cy) / f
-    r = np.sqrt(a * a + b * b) + 1e-12
-    th = np.arctan(r)
-    thd = th * (1 + strength * th ** 2 - 0.3 * strength * th ** 4)
-    m1 = (f * thd / r * a + cx).astype(np.float32)
-    m2 = (f * thd / r * b + cy).astype(np.float32)
-    k = max(32, w * h // 300)
-    ys, xs = rng.integers(0, h, k), rng.integers(0, w, k)
-    m1[ys[: k // 4], xs[: k // 4]] = np.round(m1[ys[: k // 4], xs[: k // 4]])           # integer x
-    m2[ys[k // 8: k // 3], xs[k // 8: k // 3]] = np.round(m2[ys[k // 8: k // 3], xs[k // 8: k // 3]])  # integer y (some both)
-    edge = [(-2.5, 3.0), (-1.0, -1.0), (w - 0.5, h - 0.5), (w + 1.0, 5.0), (3.0, h + 1.5), (-3.5, 2.0), (w + 2.5, 2.0),
-            (0.0, 0.0), (w - 1.0, h - 1.0), (np.nan, 4.0), (4.0, np.inf), (-np.inf, 1.0), (1e30, 2.0), (2.0, -1e30)]
-    for i, (ex, ey) in enumerate(edge):
-        m1[ys[-1 - i], xs[-1 - i]], m2[ys[-1 - i], xs[-1 - i]] = ex, ey
-    return m1, m2
+from orbfe.synth import colour_image, fisheye_maps  # noqa: E402,F401  (also used by bench.py and tests/tools/prep_latency.py)
 
 
 def py_cubic(t):
