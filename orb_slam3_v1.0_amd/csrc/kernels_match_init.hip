@@ -527,7 +527,7 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     const size_t oBin = c.take((size_t)n1 * sizeof(int));
     int n0 = 0;  // level-0 keypoints of frame 1 (:346-347): selects the kernel and sizes its candidate scratch
     for (int i = 0; i < n1; i++) n0 += F1->kp[i].octave <= 0;
-    const bool fast = n2 <= kInitN && n0 <= kFastN0;
+    bool fast = n2 <= kInitN && n0 <= kFastN0;
     const size_t oCand = c.take(fast ? (size_t)std::max(n0, 1) * n2 * sizeof(unsigned long long) : 8);
     const size_t oHdr = c.take(fast ? (size_t)std::max(n0, 1) * sizeof(InitRowHdr) : 8);
     int rc = ensure(m, c.off, inBytes + outBytes + 256, err);
@@ -564,7 +564,10 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     A.binOf = reinterpret_cast<int*>(dp + oBin);
     A.cand = reinterpret_cast<unsigned long long*>(dp + oCand);
     A.hdr = reinterpret_cast<InitRowHdr*>(dp + oHdr);
-    if (fast && !getenv("ORBFE_INIT_SLOW")) {
+#ifdef ORBFE_DIAG
+    if (getenv("ORBFE_INIT_SLOW")) fast = false;  // liborbfe_diag.so only: force the sequential block kernel
+#endif
+    if (fast) {
         if (n0 > 0) hipLaunchKernelGGL(init_cand_kernel, dim3((n0 + 3) / 4), dim3(256), 0, s, A, n0);
         hipLaunchKernelGGL(init_order_kernel, dim3(1), dim3(kInitThreads), 0, s, A, n0);
     }

@@ -863,7 +863,9 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
 #pragma unroll
                             for (int t = 0; t < 4; t++) sFbDesc[slot][t] = dp[t];
                         }
-                        atomicAdd(&A.dbg[f * 4 + 1], 1);
+#ifdef ORBFE_DIAG
+                        atomicAdd(&A.dbg[f * 4 + 1], 1);  // diagnostics build only: exact rescans of this frame
+#endif
                     }
                 }
             }
@@ -932,7 +934,9 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
                 }
                 __syncthreads();
             }
-            if (tid == 0) atomicAdd(&A.dbg[f * 4 + 0], 1);
+#ifdef ORBFE_DIAG
+            if (tid == 0) atomicAdd(&A.dbg[f * 4 + 0], 1);  // diagnostics build only: sweeps of this frame
+#endif
             if (!sChanged[iter & 1]) break;  // fixed point: T[cur] = final claims + this chunk's
             // next sweep writes its claims into the fresh copy
             const int tq = cur;
@@ -1040,7 +1044,9 @@ int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
         MCHK(hipMemsetAsync(A.nMatches, 0, (size_t)A.B * sizeof(int), s));
         return ORBFE_OK;
     }
+#ifdef ORBFE_DIAG
     MCHK(hipMemsetAsync(A.dbg, 0, (size_t)A.B * 4 * sizeof(int), s));
+#endif
     proj_prepare_launch(s, A, true);
     // Large launches: thread per map point (164 VALU + 38 SALU instructions per map point, 0.27 ms for 256 x 2000).
     // Small launches (a single frame has 8 blocks of 256 map points): the wave-per-map-point form spreads the frame's
@@ -1065,8 +1071,12 @@ int proj_launch(hipStream_t s, ProjArgs& A, std::string& err)
     // Block shape of the resolve pass: a frame is a dependent chain of sweeps, so the call is shortest with the fewest
     // chunks (1024 threads).  Frames of up to kResNDesc keypoints also stage their descriptors in LDS: the exact rescans
     // of starved map points (one wave each, ~250 per frame on the bench stream) then run out of LDS on all 16 waves.
+#ifdef ORBFE_DIAG
     static const int envT = getenv("ORBFE_RESOLVE_THREADS") ? atoi(getenv("ORBFE_RESOLVE_THREADS")) : 0;  // tuning experiments
     const int rt = envT ? envT : kResolveThreads;
+#else
+    const int rt = kResolveThreads;  // the shipped library reads no environment variable here (liborbfe_diag.so does)
+#endif
     if (lds && A.kpStride <= kResNDesc && rt == kResolveThreads) {
         hipLaunchKernelGGL((proj_resolve_kernel<true, kResolveThreads, kResNDesc, true>), dim3(A.B), dim3(kResolveThreads), 0, s, A);
     } else if (rt == 256) {
@@ -1150,11 +1160,13 @@ int match_projection_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view*
     MCHK(hipMemcpyAsync(hMatch, A.matchOut, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
     MCHK(hipMemcpyAsync(hNM, A.nMatches, sizeof(int), hipMemcpyDeviceToHost, s));
     MCHK(hipStreamSynchronize(s));
-    if (getenv("ORBFE_DEBUG_MATCH")) {  // diagnostics only
+#ifdef ORBFE_DIAG
+    if (getenv("ORBFE_DEBUG_MATCH")) {  // liborbfe_diag.so only (tools/diag_match.py, tools/resolve_stats.py)
         int dbg[4] = {0, 0, 0, 0};
         (void)hipMemcpy(dbg, A.dbg, sizeof dbg, hipMemcpyDeviceToHost);
         fprintf(stderr, "[orbfe] match_projection: n=%d M=%d sweeps=%d cooperative_rescans=%d\n", n, M, dbg[0], dbg[1]);
     }
+#endif
     memcpy(matchOut, hMatch, (size_t)n * sizeof(int));
     *nMatches = *hNM;
     return ORBFE_OK;

@@ -389,7 +389,11 @@ void launch_pyramid_level(hipStream_t s, int frames, const PipelineDesc* dP, int
 {
     // output rows per wave task: long strips amortise the per-task column setup when the launch fills the chip anyway,
     // one 4-row step per task keeps a small batch short (a task is a serial chain of steps)
-    static const int envR = getenv("ORBFE_PYR_ROWS") ? atoi(getenv("ORBFE_PYR_ROWS")) : 0;
+#ifdef ORBFE_DIAG
+    static const int envR = getenv("ORBFE_PYR_ROWS") ? atoi(getenv("ORBFE_PYR_ROWS")) : 0;  // tuning experiments (liborbfe_diag.so)
+#else
+    constexpr int envR = 0;
+#endif
     const int R = envR > 0 ? (envR + 3) & ~3 : frames >= 128 ? 8 : 4;  // strips start at multiples of four rows (x4 row-table loads)
     const int tasks = ((dh + R - 1) / R) * ((dw + 255) / 256);
     hipLaunchKernelGGL(pyramid_kernel, dim3(frames, (tasks + kPyrWaves - 1) / kPyrWaves), dim3(kPyrWaves * 64), 0, s, dP, level, R, gray0,

@@ -1,12 +1,15 @@
 """SearchForInitialization: oracle vs an independent Python restatement (no GPU) and the
 HIP kernel vs the oracle (GPU), exact indices."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
 
-import oracle_py as O
-from orbfe import synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "orb_slam3_v1.0_amd", "python"))  # when run as a script
+import oracle_py as O  # noqa: E402
+from orbfe import synth  # noqa: E402
 
 f32 = np.float32
 
@@ -142,14 +145,12 @@ def test_init_hip_equals_oracle(built, window, nn, orient, grid):
     assert n_s == n_so and np.array_equal(m_s, m_so)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("levels,nfeat,window,nn", [(1, 1000, 100, 0.9), (1, 2000, 60, 0.9), (2, 1500, 400, 0.95), (8, 1000, 1000, 0.9)])
-def test_init_fast_and_sequential_kernels_agree(built, monkeypatch, levels, nfeat, window, nn):
-    """Both device paths of orbfe_match_initialization against the oracle: the two-phase kernel (candidate keys in
-    parallel, one wave for the order-dependent part) and the sequential block kernel it replaces for large inputs.
-    One pyramid level puts every keypoint on level 0 (long candidate rows, rows that overflow the LDS image with a
-    huge window, > 1024 level-0 keypoints -> the sequential kernel is selected by the host)."""
-    import orbfe
+INIT_CASES = [(1, 1000, 100, 0.9), (1, 2000, 60, 0.9), (2, 1500, 400, 0.95), (8, 1000, 1000, 0.9),
+              (1, 3000, 100, 0.9), (1, 1100, 400, 0.95)]  # the last two: > 2048 keypoints in frame 2, > 1024 level-0 keypoints with a huge window
+
+
+def _init_case(levels, nfeat, window, nn):
+    """-> (frame views of the oracle side, GPU-side constructor arguments, reference result)"""
     W, H = 752, 480
     args = (nfeat, 40000, 1.2, levels, 20, 7, W, H)
     e = O.Extractor(*args)
@@ -160,13 +161,49 @@ def test_init_fast_and_sequential_kernels_agree(built, monkeypatch, levels, nfea
     f2 = O.make_frame_view(kp2, d2, 64, 48, 0.0, 0.0, float(W), float(H), e.scaleFactors)
     n_ref, m_ref = O.search_for_initialization(f1, f2, window, nn, True)
     assert n_ref > 20
+    return args, (kp1, d1, kp2, d2), (n_ref, m_ref)
+
+
+def _init_gpu(orbfe, args, kd, window, nn):
+    W, H = args[6], args[7]
+    kp1, d1, kp2, d2 = kd
     ex = orbfe.ORBextractor(*args, device=0, max_batch=1)
     g1 = orbfe.make_frame_view(kp1, d1, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
     g2 = orbfe.make_frame_view(kp2, d2, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
-    for slow in ("", "1"):
-        if slow:
-            monkeypatch.setenv("ORBFE_INIT_SLOW", "1")
-        else:
-            monkeypatch.delenv("ORBFE_INIT_SLOW", raising=False)
-        n, m = orbfe.ORBmatcher(ex).SearchForInitialization(g1, g2, window, nn, True)
-        assert n == n_ref and np.array_equal(m, m_ref), slow
+    return orbfe.ORBmatcher(ex).SearchForInitialization(g1, g2, window, nn, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels,nfeat,window,nn", INIT_CASES)
+def test_init_fast_and_sequential_kernels_agree(built, levels, nfeat, window, nn):
+    """Both device paths of orbfe_match_initialization against the oracle, selected by the host from the input sizes as in
+    production: the two-phase kernel (candidate keys in parallel, one wave for the order-dependent part) and the
+    sequential block kernel that takes over for large inputs.  One pyramid level puts every keypoint on level 0 (long
+    candidate rows, rows that overflow the LDS image with a huge window; > 1024 level-0 keypoints or > 2048 keypoints in
+    frame 2 -> the sequential kernel)."""
+    import orbfe
+    args, kd, (n_ref, m_ref) = _init_case(levels, nfeat, window, nn)
+    n, m = _init_gpu(orbfe, args, kd, window, nn)
+    assert n == n_ref and np.array_equal(m, m_ref)
+
+
+@pytest.mark.gpu
+def test_init_sequential_kernel_forced_on_small_inputs(built):
+    """The sequential kernel on the inputs the fast kernel normally takes.  The switch that forces it (ORBFE_INIT_SLOW)
+    exists only in the diagnostics build liborbfe_diag.so (`make diag`, -DORBFE_DIAG) -- the shipped library reads no such
+    variable -- so this runs once in a child process that loads that build."""
+    import subprocess
+    env = dict(os.environ, ORBFE_INIT_SLOW="1", ORBFE_TEST_LIB="liborbfe_diag.so")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "forced sequential kernel: 4 cases exact" in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
+
+
+if __name__ == "__main__":  # child of test_init_sequential_kernel_forced_on_small_inputs
+    import orbfe
+    orbfe.LIB_PATH = os.path.join(orbfe.CSRC, os.environ["ORBFE_TEST_LIB"])
+    assert os.environ.get("ORBFE_INIT_SLOW") == "1"
+    for case in INIT_CASES[:4]:
+        a, kd, (n_ref, m_ref) = _init_case(*case)
+        n, m = _init_gpu(orbfe, a, kd, case[2], case[3])
+        assert n == n_ref and np.array_equal(m, m_ref), case
+    print("forced sequential kernel: 4 cases exact")

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Diagnostics: replay the bench's match scenario for a few frames through the host API with
-ORBFE_DEBUG_MATCH=1 (prints sweeps / cooperative rescans), and time the call."""
+the diagnostics build (make diag) and ORBFE_DEBUG_MATCH=1 (prints sweeps / cooperative rescans), and time the call."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "orb_slam3_v1.0_amd", "python")); sys.path.insert(0, ROOT)
 os.environ["ORBFE_DEBUG_MATCH"] = "1"
 import numpy as np
 import orbfe
+orbfe.LIB_PATH = os.path.join(orbfe.CSRC, "liborbfe_diag.so")  # the counters exist only in the -DORBFE_DIAG build (make diag)
 from orbfe import synth
 import bench
 cfg = bench.WORKLOADS["euroc_752x480"]

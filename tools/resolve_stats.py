@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweeps and exact rescans of proj_resolve_kernel on frames of the bench stream (host entry point, ORBFE_DEBUG_MATCH)."""
+"""Sweeps and exact rescans of proj_resolve_kernel on frames of the bench stream (host entry point; liborbfe_diag.so + ORBFE_DEBUG_MATCH)."""
 import os
 import sys
 
@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import bench  # noqa: E402
 import orbfe  # noqa: E402
+orbfe.LIB_PATH = os.path.join(orbfe.CSRC, "liborbfe_diag.so")  # the counters exist only in the -DORBFE_DIAG build (make diag)
 from orbfe import synth  # noqa: E402
 
 ARGS = (1000, 40000, 1.2, 8, 20, 7, 752, 480)
