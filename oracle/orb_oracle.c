@@ -122,7 +122,14 @@ float orc_spec_atan2f(float y, float x)
 /* src/cuda/Angle_gpu.cu:73-75 : atan2f -> +2pi if negative -> degrees */
 float orc_atan2_deg(float m01, float m10)
 {
+#ifdef ORC_LIBM
+    /* S5 distance study only (tools/s5_libm_study.py, liborb_oracle_libm.so): the host libm's atan2f in place of the
+     * specified polynomial -- glibc is correctly rounded to < 1 ulp, the CUDA libm the reference runs is documented to
+     * 2 ulp, so this is ONE admissible outcome of the reference's line, not "the" reference value */
+    float kp_dir = atan2f(m01, m10);
+#else
     float kp_dir = orc_spec_atan2f(m01, m10);
+#endif
     if (kp_dir < 0.0f) kp_dir = kp_dir + 2.0f * F_PI;
     kp_dir = kp_dir * (180.0f / F_PI);
     return kp_dir;
@@ -131,6 +138,14 @@ float orc_atan2_deg(float m01, float m10)
 /* replaces cosf/sinf(angle * factorPI) of src/cuda/Orb_gpu.cu:327-329 */
 void orc_cos_sin_deg(float deg, float *c, float *s)
 {
+#ifdef ORC_LIBM
+    {   /* S5 distance study only: the literal src/cuda/Orb_gpu.cu:327-329 on the host libm */
+        const float angle = deg * F_DEG2RAD;
+        *c = cosf(angle);
+        *s = sinf(angle);
+        return;
+    }
+#endif
     float kf = deg * F_INV90;
     kf = kf + 0.5f;
     int k = (int)kf;

@@ -58,6 +58,10 @@ def lib():
         srcs = ("orb_oracle.c", "match_oracle.c", "prep_oracle.c", "orb_oracle.h")
         if os.environ.get("ORB_ORACLE_ASAN"):  # tests/test_oracle_asan.py: the sanitizer build of the same sources
             path = build(asan=True)
+        elif os.environ.get("ORB_ORACLE_VARIANT"):  # tools/s5_libm_study.py: liborb_oracle_libm.so (-DORC_LIBM), never the parity authority
+            target = "liborb_oracle_%s.so" % os.environ["ORB_ORACLE_VARIANT"]
+            subprocess.check_call(["make", "-s", "-C", ODIR, target])
+            path = os.path.join(ODIR, target)
         elif not os.path.exists(path) or any(
                 os.path.getmtime(os.path.join(ODIR, f)) > os.path.getmtime(path) for f in srcs):
             build()
