@@ -50,11 +50,8 @@ constexpr int kScPitch = kImgW;
 constexpr int kScoreOfs = 3 * kImgW + 3;                  // score (sy, sx) <-> staged pixel (sy + 3, sx + 3)
 constexpr int kMaxTileCand = (kFastTW / 2) * (kFastTH / 2);  // strict 8-neighbour maxima: <= 1 per 2x2
 constexpr int kTmpH = kFastTH + 4;                        // 36 rows of horizontal blur sums
-// stage A geometry: 18 column groups of 4 staged columns x 7 strips of 5 score rows
-constexpr int kGroups = kImgW / 4, kStripRows = 5, kStrips = (kScH + kStripRows - 1) / kStripRows;
-constexpr int kTasks = kGroups * kStrips;                 // 126 lanes of waves 0 and 1
 constexpr int kQCap = 2304;                               // queue A slots (>= 66 * 34), even
-static_assert(kTasks <= 128 && kQCap >= kScH * kScW && kQCap % 2 == 0, "stage A geometry");
+static_assert(kQCap >= kScH * kScW && kQCap % 2 == 0, "stage A geometry");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
@@ -251,6 +248,103 @@ __device__ __forceinline__ int queue_slot(uint32_t m, int th, unsigned long long
     return cnt;
 }
 
+// ---- round 3: the 16-bit VOP2 instructions below belong to the fast group of this chip (tools/valu_rate.hip,
+// profiles/r03_valu_rate.txt: v_min_u16 / v_max_u16 / v_sub_u16 / v_min_i16, like v_add_u32 / v_and / v_or / v_xor / v_sub,
+// retire in ~2.3 cycles per wave64 instruction; the packed v_pk_* forms, v_perm, v_lshl_or, three-input and 32-bit
+// min / max take ~4.2).  One pixel per lane on the fast instructions costs what two pixels per lane cost on the packed
+// ones -- without the byte-pair packing, the pair bookkeeping and the per-half predicates.  Inline assembly because
+// hipcc widens 16-bit min / max to the slow 32-bit forms.  Operands are 0..255 (or small signed differences) in 32-bit
+// registers; only the low 16 bits of a result are ever consumed.
+__device__ __forceinline__ uint32_t min16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t max16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub16(uint32_t a, uint32_t b)  // a - b, 16-bit two's complement
+{
+    uint32_t r;
+    asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t maxi16(uint32_t a, uint32_t b)  // signed
+{
+    uint32_t r;
+    asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// max over the sixteen 9-arcs of the arc minimum of ONE pixel's ring p[0..15] (values 0..255): the same prefix / suffix
+// scheme as arc_extreme above, 42 v_min_u16 + 15 v_max_u16.  The dark polarity goes through the same network on the
+// inverted ring (255 - p): v - min over arcs of the arc maximum == (max over arcs of the arc minimum of 255 - p) - (255 - v).
+__device__ __forceinline__ uint32_t arc_max_of_min(const uint32_t (&p)[16])
+{
+    uint32_t S[16], Pf[16];
+    S[7] = p[7];
+    S[15] = p[15];
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+        S[k] = min16(p[k], S[k + 1]);
+        S[k + 8] = min16(p[k + 8], S[k + 9]);
+    }
+    Pf[0] = p[0];
+    Pf[8] = p[8];
+#pragma unroll
+    for (int k = 1; k < 7; k++) {
+        Pf[k] = min16(p[k], Pf[k - 1]);
+        Pf[k + 8] = min16(p[k + 8], Pf[k + 7]);
+    }
+    Pf[7] = S[0];
+    Pf[15] = S[8];
+    uint32_t a[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        a[k] = min16(S[k], Pf[k + 8]);
+        a[k + 8] = min16(S[k + 8], Pf[k]);
+    }
+#pragma unroll
+    for (int st = 8; st >= 1; st >>= 1)
+#pragma unroll
+        for (int k = 0; k < st; k++) a[k] = max16(a[k], a[k + st]);
+    return a[0];
+}
+
+// lane mask of th < (signed 16-bit) m, through VCC (the e32 compare)
+__device__ __forceinline__ unsigned long long mask_th_i16(int th, uint32_t m)
+{
+    unsigned long long r;
+    asm("v_cmp_lt_i16_e64 %0, %1, %2" : "=s"(r) : "s"(th), "v"(m));
+    return r;
+}
+
+// One compaction step of stage A (one pixel per lane): the lanes of `mask` whose signed 16-bit margin m exceeds th append
+// `entry` (the staged byte offset of their pixel) to the queue at byte address qNext + rank * step; returns how many did.
+__device__ __forceinline__ int queue_slot1(uint32_t m, int th, unsigned long long mask, uint32_t entry, int stepV, int qNext)
+{
+    unsigned long long save;
+    uint32_t tmp;
+    int cnt;
+    asm volatile("v_cmp_lt_i16_e32 vcc, %8, %3\n\t"
+                 "s_and_b64 vcc, vcc, %4\n\t"
+                 "s_and_saveexec_b64 %0, vcc\n\t"
+                 "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
+                 "v_mad_i32_i24 %1, %1, %6, %7\n\t"
+                 "ds_write_b16 %1, %5\n\t"
+                 "s_mov_b64 exec, %0\n\t"
+                 "s_bcnt1_i32_b64 %2, vcc"
+                 : "=&s"(save), "=&v"(tmp), "=s"(cnt)
+                 : "v"(m), "s"(mask), "v"(entry), "v"(stepV), "s"(qNext), "s"(th)
+                 : "vcc", "scc", "memory");
+    return cnt;
+}
+
 // MODE is a timing-only ablation switch (bit 0 = Gaussian, bit 1 = FAST, bit 2 = stop after stage A, bit 3 = stop
 // after stage B); the shipped library instantiates MODE 3 only -- the other variants exist in the -DORBFE_ABLATION
 // build (`make ablation`) used by tools/fast_stage_*.sh.
@@ -277,7 +371,11 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     // barrier (after stage A) separates its last read from the first corner-queue write
     static_assert(sizeof(uint16_t) * kScH * kScW <= sizeof(uint32_t) * (kTmpH / 2) * kFastTW, "corner queue must fit the blur buffer");
     uint16_t* const sQB = reinterpret_cast<uint16_t*>(&sTmp[0][0]);
-    __shared__ uint32_t sQ[3];  // entries of queue A by wave 0 / wave 1, corner-queue entries
+    __shared__ uint32_t sQ[4];  // entries of queue A by wave 0 / wave 1, corner-queue entries, entries of sBoth
+    // pixels of stage B that need BOTH polarities (their dark pass runs in the main sweep, the bright one in a second,
+    // dense sweep over this list); entries beyond the capacity are finished inside the main sweep instead
+    constexpr int kBothCap = 256;
+    __shared__ uint16_t sBoth[kBothCap];
 
     const int f = blockIdx.x;
     const int tile = blockIdx.y;
@@ -307,7 +405,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     if (tid < 4) sCnt[tid] = 0;
-    if (tid < 3) sQ[tid] = 0;
+    if (tid < 4) sQ[tid] = 0;
     if (tid < kFastTH) sRow[tid] = 0;
 
     // ---- stage the 72 x 40 tile (origin x0-4, y0-4).  Thread -> fixed dword column c4 (18 per row) and
@@ -421,6 +519,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, provably uniform
     if (wv >= 2) {
         // waves 2 and 3 clear the score map and run the Gaussian's vertical pass while waves 0 and 1 run stage A
+        // (spreading all three over the four waves -- 9/8/9/8-row strips, four queue segments -- was measured: 1 % slower)
         if constexpr ((MODE & 2) != 0)
             for (int e = tid - 128; e < (kScH + 1) * (kScPitch / 4); e += 128) reinterpret_cast<uint32_t*>(&sScore[0][0])[e] = 0;
         if constexpr ((MODE & 1) != 0) {
@@ -475,67 +574,64 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         //      positions always contain two ADJACENT compass points, the compass cycle 0-4-8-12 is bipartite
         //      ({0,8} vs {4,12}) and every cross pair is adjacent, so a corner needs
         //      min(max(N,S), max(E,W)) > v + th  or  max(min(N,S), min(E,W)) < v - th.
-        //      Lane = (column group g of 4 staged columns, strip s of 5 score rows); values are 16-bit pairs of
-        //      horizontally adjacent pixels, so every packed instruction tests two positions ----
-        const int t = tid;
-        const int s = min(t / kGroups, kStrips - 1);
-        const int g = t - (t / kGroups) * kGroups;
-        const uint8_t* base = &sImg[kStripRows * s][4 * g];  // staged rows 5s .. 5s+10
-        uint32_t ca[kStripRows + 6], cb[kStripRows + 6];     // centre pairs (cols 0,1) and (cols 2,3) of the 11 rows
-#pragma unroll
-        for (int i = 0; i < kStripRows + 6; i++) {
-            const uint32_t d1 = *reinterpret_cast<const uint32_t*>(base + i * kImgW);
-            ca[i] = __builtin_amdgcn_perm(0u, d1, 0x0c010c00u);
-            cb[i] = __builtin_amdgcn_perm(0u, d1, 0x0c030c02u);
-        }
-        uint32_t marg[kStripRows][2];  // per 16-bit half: max(bright, dark) margin of that position; it passes iff > minTh
-#pragma unroll
-        for (int i = 0; i < kStripRows; i++) {
-            const uint8_t* rp = base + (i + 3) * kImgW;
-            const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rp - 4);
-            const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rp);
-            const uint32_t d2 = *reinterpret_cast<const uint32_t*>(rp + 4);
-            const uint32_t ea = __builtin_amdgcn_perm(d2, d1, 0x0c040c03u);  // cols 3,4
-            const uint32_t eb = __builtin_amdgcn_perm(d2, d1, 0x0c060c05u);  // cols 5,6
-            const uint32_t wa = __builtin_amdgcn_perm(d1, d0, 0x0c020c01u);  // cols -3,-2
-            const uint32_t wb = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);  // cols -1,0
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const uint32_t n = p ? cb[i] : ca[i], so = p ? cb[i + 6] : ca[i + 6], c = p ? cb[i + 3] : ca[i + 3];
-                const uint32_t e = p ? eb : ea, wq = p ? wb : wa;
-                const uint32_t hiPair = pk_min_u(pk_max_u(n, so), pk_max_u(e, wq));
-                const uint32_t loPair = pk_max_u(pk_min_u(n, so), pk_min_u(e, wq));
-                marg[i][p] = pk_max_i(pk_sub(hiPair, c), pk_sub(c, loPair));
-            }
-        }
-        // validity of the lane's 4 columns / 5 rows as lane masks: staged column c is tested iff cLo <= c <= cHi
-        // (score columns 0..65 inside the FAST region kEdge < x < w - kEdge), staged row r iff rLo <= r <= rHi
+        //      ONE pixel per lane on the fast 16-bit instructions: lane = staged column 3 + lane, wave 0 walks the score
+        //      rows 0..16 and wave 1 the rows 17..33 down that column with the seven column values (N, centre, S of
+        //      the last rows) kept in registers -- three byte loads (W, E, the row three below) and nine arithmetic
+        //      instructions per pixel; the two remaining score columns 64 and 65 are one extra step (lane = row) ----
+        constexpr int kRowsA = kScH / 2;
+        static_assert(2 * kRowsA == kScH && kScW == 66, "stage A geometry");
+        const int R0 = wv ? 3 + kRowsA : 3;  // first staged row of this wave's strip
+        // validity as lane / scalar masks: staged column c is tested iff cLo <= c <= cHi (score columns 0..65 inside the
+        // FAST region kEdge < x < w - kEdge), staged row r iff rLo <= r <= rHi
         const int cLo = max(3, kEdge + 1 - (x0 - 4)), cHi = min(kScW + 2, w - kEdge - 1 - (x0 - 4));
         const int rLo = max(3, kEdge + 1 - (y0 - 4)), rHi = min(kScH + 2, h - kEdge - 1 - (y0 - 4));
         const uint32_t cSpan = (uint32_t)max(cHi - cLo, -1), rSpan = (uint32_t)max(rHi - rLo, -1);  // -1: nothing valid
-        const uint32_t cRel = t < kTasks ? (uint32_t)(4 * g - cLo) : 0x40000000u;
-        const uint32_t rRel = (uint32_t)(kStripRows * s + 3 - rLo);
-        unsigned long long colOK[4], rowOK[kStripRows];
-#pragma unroll
-        for (int j = 0; j < 4; j++) colOK[j] = cSpan == 0xffffffffu ? 0ull : mask_le_u32(cRel + j, cSpan);
-#pragma unroll
-        for (int i = 0; i < kStripRows; i++) rowOK[i] = rSpan == 0xffffffffu ? 0ull : mask_le_u32(rRel + i, rSpan);
+        const bool anyValid = cSpan != 0xffffffffu && rSpan != 0xffffffffu;
+        const unsigned long long colOK = anyValid ? mask_le_u32((uint32_t)(lane + 3 - cLo), cSpan) : 0ull;
         // compaction: wave 0 writes slots 0, 1, ... ; wave 1 writes slots kQCap-1, kQCap-2, ... -- the byte address of
         // the wave's next slot lives in a scalar, +-2 per entry (no reservation, no atomics)
-        const int e0 = (kStripRows * s + 3) * kImgW + 4 * g;  // staged byte offset of the lane's first position
         const int qStep = wv ? -2 : 2;
         const int qStepV = (tid & 64) ? -2 : 2;  // the same in a vector register (one SGPR operand per VOP3 on gfx9)
         const int qBase = (int)(reinterpret_cast<uintptr_t>(&sQA[0]) & 0xffffu);  // LDS byte address of the queue
         int qNext = qBase + (wv ? 2 * (kQCap - 1) : 0);
         uint32_t nq = 0;
-        const uint32_t e0Pair = (uint32_t)e0 * 0x00010001u + 0x00010000u;  // offsets of columns (0, 1) as a 16-bit pair (< 2^16: no carry)
+        const uint8_t* base = &sImg[R0 - 3][lane];  // staged column c - 3 of the strip's first window row: W +0, column c +3, E +6
+        uint32_t entry = (uint32_t)(R0 * kImgW + 3) + (uint32_t)lane;  // staged byte offset of the lane's pixel
+        uint32_t col[7];  // sliding window: column values of staged rows r-3 .. r+3 (slot = window row mod 7)
 #pragma unroll
-        for (int i = 0; i < kStripRows; i++) {
+        for (int k = 0; k < 6; k++) col[k] = base[k * kImgW + 3];
+        uint32_t wN = base[3 * kImgW], eN = base[3 * kImgW + 6], sN = base[6 * kImgW + 3];  // requested one row ahead
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t entryPair = e0Pair + (uint32_t)(i * kImgW + (j & 2)) * 0x00010001u;  // one add per column pair
-                const int cnt = (j & 1) ? queue_slot<true>(marg[i][j >> 1], minTh, colOK[j], rowOK[i], entryPair, qStepV, qNext)
-                                        : queue_slot<false>(marg[i][j >> 1], minTh, colOK[j], rowOK[i], entryPair, qStepV, qNext);
+        for (int i = 0; i < kRowsA; i++) {
+            const uint32_t wq = wN, e = eN;
+            col[(i + 6) % 7] = sN;
+            if (i + 1 < kRowsA) {
+                wN = base[(i + 4) * kImgW];
+                eN = base[(i + 4) * kImgW + 6];
+                sN = base[(i + 7) * kImgW + 3];
+            }
+            const uint32_t n = col[i % 7], c = col[(i + 3) % 7], so = col[(i + 6) % 7];
+            const uint32_t hiV = min16(max16(n, so), max16(e, wq));
+            const uint32_t loV = max16(min16(n, so), min16(e, wq));
+            const uint32_t marg = maxi16(sub16(hiV, c), sub16(c, loV));  // max(bright, dark) margin: passes iff > minTh
+            const unsigned long long rowMask = (uint32_t)(R0 + i - rLo) <= rSpan ? colOK : 0ull;  // scalar select
+            const int cnt = queue_slot1(marg, minTh, rowMask, entry, qStepV, qNext);
+            entry += (uint32_t)kImgW;
+            nq += (uint32_t)cnt;
+            qNext += cnt * qStep;
+        }
+        {
+            // score columns 64 / 65 (staged columns 67 / 68): wave 0 / wave 1, lane = score row
+            const int cx = kScW + 1 + wv;
+            if (anyValid && (uint32_t)(cx - cLo) <= cSpan) {  // wave-uniform
+                const int rr = min(lane, kScH - 1) + 3;
+                const uint8_t* pc = &sImg[rr][cx];
+                const uint32_t n = pc[-3 * kImgW], so = pc[3 * kImgW], c = pc[0], e = pc[3], wq = pc[-3];
+                const uint32_t hiV = min16(max16(n, so), max16(e, wq));
+                const uint32_t loV = max16(min16(n, so), min16(e, wq));
+                const uint32_t marg = maxi16(sub16(hiV, c), sub16(c, loV));
+                const unsigned long long m = mask_le_u32((uint32_t)lane, kScH - 1) & mask_le_u32((uint32_t)(rr - rLo), rSpan);
+                const int cnt = queue_slot1(marg, minTh, m, (uint32_t)(rr * kImgW + cx), qStepV, qNext);
                 nq += (uint32_t)cnt;
                 qNext += cnt * qStep;
             }
@@ -546,59 +642,127 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
 
     if constexpr ((MODE & 2) != 0) {
     __syncthreads();
-    // ---- stage B: segment test + corner score of two queued pixels per lane; corners -> score map + corner queue ----
+    if constexpr ((MODE & 64) != 0) {
+        // timing experiment (ablation build only): 128 independent packed instructions per lane on every wave.  If the kernel
+        // is bound by vector issue its time grows by what they cost on a saturated SIMD; if it is bound by the waves' own
+        // dependency / barrier chains it grows by a few per cent
+        uint32_t d[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = (uint32_t)tid * 2654435761u + (uint32_t)i;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if constexpr ((MODE & 128) != 0) asm volatile("v_max_u16 %0, %1, %0" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));  // fast-group opcode
+                else asm volatile("v_pk_max_u16 %0, %1, %0" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+            }
+        if ((d[0] ^ d[1] ^ d[2] ^ d[3] ^ d[4] ^ d[5] ^ d[6] ^ d[7]) == 0x12345u) sCnt[0] = 1;
+    }
+    // ---- stage B: segment test + corner score, one queued pixel per lane; corners -> score map + corner queue.
+    //      Only ONE polarity is evaluated per pixel: a dark corner needs the dark compass test, a bright corner the bright
+    //      one, so a pixel whose dark compass test passes is scored on the inverted ring (255 - p: the same network,
+    //      arc_max_of_min) and every other pixel on the ring itself.  A pixel that passes BOTH compass tests (two compass
+    //      neighbours brighter, the two opposite ones darker: ~3 % of the queue on the bench stream, i.e. some lane of
+    //      almost every wave) is scored dark here and goes to the block's list sBoth, which a second, dense sweep scores
+    //      bright -- at most one of the two can be a corner, so each sweep simply records the corners it finds ----
     if constexpr ((MODE & 4) == 0) {
         const int n0 = __builtin_amdgcn_readfirstlane((int)sQ[0]), n1 = __builtin_amdgcn_readfirstlane((int)sQ[1]);
-        const int np0 = (n0 + 1) >> 1, npT = np0 + ((n1 + 1) >> 1);
-        const uint32_t* qd = reinterpret_cast<const uint32_t*>(sQA);
+        const int nA = n0 + n1;
         const uint8_t* img = &sImg[0][0];
         const uint32_t scoreLds = (uint32_t)(uintptr_t)&sScore[0][0] - (uint32_t)kScoreOfs, qbLds = (uint32_t)(uintptr_t)&sQB[0];
-#pragma unroll 1
-        for (int q0 = wv * 64; q0 < npT; q0 += 256) {   // wave-uniform trip count
-            const int q = q0 + lane;
-            const bool act = q < npT;
-            const bool seg1 = q >= np0;
-            // wave 0's pair q = slots 2q, 2q+1; wave 1's pair q' = slots kQCap-1-2q', kQCap-2-2q' = dword kQCap/2-1-q'
-            uint32_t e01 = act ? qd[seg1 ? kQCap / 2 - 1 - (q - np0) : q] : (uint32_t)kScoreOfs * 0x00010001u;
-            if (seg1) e01 = __builtin_amdgcn_alignbit(e01, e01, 16);  // first entry of the pair in the low half
-            // second pixel of the pair present?  (false for inactive lanes too)
-            const unsigned long long mask_two = mask_lt_i32((uint32_t)(seg1 ? 2 * (q - np0) + 1 : 2 * q + 1), seg1 ? n1 : n0, true);
-            const uint32_t eA = e01 & 0xffffu;
-            const uint32_t eB = select_by_mask(mask_two, e01 >> 16, eA);
-            const uint8_t* pa = img + eA;  // centre of pixel A in the staged tile
-            const uint8_t* pb = img + eB;
-            // ring position k <-> (dy, dx): 0:(3,0) 1:(3,1) 2:(2,2) 3:(1,3) 4:(0,3) 5:(-1,3) 6:(-2,2) 7:(-3,1) 8:(-3,0)
-            // 9:(-3,-1) 10:(-2,-2) 11:(-1,-3) 12:(0,-3) 13:(1,-3) 14:(2,-2) 15:(3,-1)
-            constexpr int ro[16] = {3 * kImgW,      3 * kImgW + 1,  2 * kImgW + 2,  kImgW + 3,  3,  -kImgW + 3, -2 * kImgW + 2, -3 * kImgW + 1,
-                                    -3 * kImgW,     -3 * kImgW - 1, -2 * kImgW - 2, -kImgW - 3, -3, kImgW - 3,  2 * kImgW - 2,  3 * kImgW - 1};
-            uint32_t p[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) p[k] = (uint32_t)pa[ro[k]] | ((uint32_t)pb[ro[k]] << 16);
-            const uint32_t v = (uint32_t)pa[0] | ((uint32_t)pb[0] << 16);
-            const uint32_t hi = pk_sub(arc_extreme<false>(p), v);
-            const uint32_t lo = pk_sub(v, arc_extreme<true>(p));
-            const uint32_t margin = pk_max_i(hi, lo);
-            // corners as lane masks straight from the compares (low half: 16-bit compare, high half through SDWA); a lane
-            // (half) without a pixel is masked out
-            const unsigned long long ma = mask_lt_i32((uint32_t)q, npT) & mask_th_lo(minTh, margin);
-            const unsigned long long mb = mask_two & mask_th_hi(minTh, margin);
-            // score - 1 of both halves with one subtraction: ds_write_b8 stores bits 7..0, ds_write_b8_d16_hi bits 23..16
-            const uint32_t sc1 = pk_sub(margin, 0x00010001u);
-            masked_lds_write_b8(ma, scoreLds + eA, sc1);
-            masked_lds_write_b8_hi(mb, scoreLds + eB, sc1);
-            // corner queue: one reservation per wave for both halves
-            const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
-            if (na + nb) {  // wave-uniform
+        const uint32_t bothLds = (uint32_t)(uintptr_t)&sBoth[0];
+        constexpr uint32_t kIdle = (uint32_t)(20 * kImgW + 36);  // an interior position: lanes without a pixel read valid LDS
+        uint32_t kFF = 0xffu;
+        asm("" : "+v"(kFF));
+        // ring position k <-> (dy, dx): 0:(3,0) 1:(3,1) 2:(2,2) 3:(1,3) 4:(0,3) 5:(-1,3) 6:(-2,2) 7:(-3,1) 8:(-3,0)
+        // 9:(-3,-1) 10:(-2,-2) 11:(-1,-3) 12:(0,-3) 13:(1,-3) 14:(2,-2) 15:(3,-1)
+        constexpr int ro[16] = {3 * kImgW,      3 * kImgW + 1,  2 * kImgW + 2,  kImgW + 3,  3,  -kImgW + 3, -2 * kImgW + 2, -3 * kImgW + 1,
+                                -3 * kImgW,     -3 * kImgW - 1, -2 * kImgW - 2, -kImgW - 3, -3, kImgW - 3,  2 * kImgW - 2,  3 * kImgW - 1};
+        // corners of the lanes in `mc`: score - 1 into the score map, the pixel into the corner queue (one reservation per wave)
+        auto record = [&](unsigned long long mc, uint32_t e, uint32_t margin) {
+            masked_lds_write_b8(mc, scoreLds + e, sub16(margin, 1u));
+            const uint32_t nc = (uint32_t)__popcll(mc);
+            if (nc) {  // wave-uniform
                 uint32_t qb = 0;
-                if (lane == 0) qb = lds_add_rtn(&sQ[2], na + nb);
+                if (lane == 0) qb = lds_add_rtn(&sQ[2], nc);
                 qb = __builtin_amdgcn_readfirstlane(qb);
-                const uint32_t ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
-                const uint32_t rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
-                masked_lds_write_b16(ma, qbLds + 2u * (qb + ra), eA);
-                masked_lds_write_b16(mb, qbLds + 2u * (qb + na + rb), eB);
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, 0u));
+                masked_lds_write_b16(mc, qbLds + 2u * (qb + rk), e);
             }
+        };
+#pragma unroll 1
+        for (int i0 = wv * 64; i0 < nA; i0 += 256) {   // wave-uniform trip count
+            const int i = i0 + lane;
+            // wave 0's entry i = slot i; wave 1's entry j = slot kQCap - 1 - j
+            uint32_t e = kIdle;
+            if (i < nA) e = sQA[i < n0 ? i : kQCap - 1 + n0 - i];
+            const uint8_t* pc = img + e;  // centre of the pixel in the staged tile
+            uint32_t p[16];
+            const uint32_t v = pc[0];
+            if constexpr ((MODE & 32) != 0) {  // timing experiment: no ring loads
+#pragma unroll
+                for (int k = 0; k < 16; k++) p[k] = v + (uint32_t)((k * 37) & 63);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) p[k] = pc[ro[k]];
+            }
+            // compass margins of both polarities (the tests stage A merged): which network does this pixel need?
+            const uint32_t bm = sub16(min16(max16(p[0], p[8]), max16(p[4], p[12])), v);
+            const uint32_t dm = sub16(v, max16(min16(p[0], p[8]), min16(p[4], p[12])));
+            const unsigned long long mAct = mask_lt_i32((uint32_t)i, nA);
+            const unsigned long long mDark = mask_th_i16(minTh, dm);
+            unsigned long long mBoth = mDark & mask_th_i16(minTh, bm) & mAct;
+            const uint32_t inv = select_by_mask(mDark, kFF, 0u);
+            uint32_t q[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) q[k] = p[k] ^ inv;
+            const uint32_t vi = v ^ inv;
+            // margin by which the best 9-arc clears the centre: corner at threshold th iff margin > th (the segment test of
+            // Fast_gpu.cu:222-267), and margin - 1 is the score the reference finds by binary search (:193-216)
+            uint32_t margin;
+            if constexpr ((MODE & 16) != 0) {  // timing experiment: no arc network
+                uint32_t acc = q[0];
+#pragma unroll
+                for (int k = 1; k < 16; k++) acc ^= q[k];
+                margin = sub16(acc & 0xffu, vi);
+            } else {
+                margin = sub16(arc_max_of_min(q), vi);
+            }
+            if (mBoth != 0) {  // wave-uniform: hand the pixels over to the bright sweep
+                const uint32_t nb = (uint32_t)__popcll(mBoth);
+                uint32_t bb = 0;
+                if (lane == 0) bb = lds_add_rtn(&sQ[3], nb);
+                bb = __builtin_amdgcn_readfirstlane(bb);
+                const uint32_t pos = bb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mBoth >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mBoth, 0u));
+                const unsigned long long mFit = mBoth & mask_le_u32(pos, kBothCap - 1);
+                masked_lds_write_b16(mFit, bothLds + 2u * pos, e);
+                mBoth &= ~mFit;
+                if (mBoth != 0) {  // list full (only on contrived images): finish these pixels here -- the max of both polarities is exact
+                    uint32_t r[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) r[k] = q[k] ^ kFF;
+                    margin = select_by_mask(mBoth, maxi16(margin, sub16(arc_max_of_min(r), vi ^ kFF)), margin);  // listed lanes keep the dark margin
+                }
+            }
+            record(mAct & mask_th_i16(minTh, margin), e, margin);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the masked LDS stores above are not counted by the compiler
+        __syncthreads();
+        // second sweep: the bright polarity of the pixels that passed both compass tests
+        const int nBoth = min((int)sQ[3], kBothCap);
+#pragma unroll 1
+        for (int i0 = wv * 64; i0 < nBoth; i0 += 256) {   // wave-uniform; usually one pass of wave 0
+            const int i = i0 + lane;
+            uint32_t e = kIdle;
+            if (i < nBoth) e = sBoth[i];
+            const uint8_t* pc = img + e;
+            uint32_t p[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) p[k] = pc[ro[k]];
+            const uint32_t margin = sub16(arc_max_of_min(p), (uint32_t)pc[0]);
+            record(mask_lt_i32((uint32_t)i, nBoth) & mask_th_i16(minTh, margin), e, margin);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
     const int nB = (MODE & 8) ? 0 : (int)sQ[2];
@@ -626,10 +790,10 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             if (mPre == 0) continue;  // wave-uniform
             const uint8_t* sp = &sScore[0][0] + (e - kScoreOfs);
             const uint32_t sc = sp[0];
-            const uint32_t n0 = max(max((uint32_t)sp[-kScPitch - 1], (uint32_t)sp[-kScPitch]), (uint32_t)sp[-kScPitch + 1]);
-            const uint32_t n1 = max(max((uint32_t)sp[-1], (uint32_t)sp[1]), (uint32_t)sp[kScPitch - 1]);
-            const uint32_t n2 = max((uint32_t)sp[kScPitch], (uint32_t)sp[kScPitch + 1]);
-            const uint32_t nmax = max(max(n0, n1), n2);  // strictly greater than all eight == greater than their maximum
+            const uint32_t n0 = max16(max16((uint32_t)sp[-kScPitch - 1], (uint32_t)sp[-kScPitch]), (uint32_t)sp[-kScPitch + 1]);
+            const uint32_t n1 = max16(max16((uint32_t)sp[-1], (uint32_t)sp[1]), (uint32_t)sp[kScPitch - 1]);
+            const uint32_t n2 = max16((uint32_t)sp[kScPitch], (uint32_t)sp[kScPitch + 1]);
+            const uint32_t nmax = max16(max16(n0, n1), n2);  // strictly greater than all eight == greater than their maximum
             const unsigned long long mHi = mask_ge_u32(sc, (uint32_t)iniTh);
             const unsigned long long mKeep = mPre & mask_gt_u32(sc, nmax);
             const unsigned long long mPreHi = mPre & mHi, mKeepHi = mKeep & mHi;
@@ -703,7 +867,7 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
     // RESULTS ARE WRONG unless it is 3.  The shipped library does not contain these variants and reads no variable.
     static const int mode = [] {
         const char* e = getenv("ORBFE_FAST_MODE");
-        return e ? atoi(e) & 15 : 3;
+        return e ? atoi(e) & 255 : 3;
     }();
     switch (mode) {
     case 0: ORBFE_LAUNCH_FB(0); break;
@@ -711,6 +875,10 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
     case 2: ORBFE_LAUNCH_FB(2); break;
     case 6: ORBFE_LAUNCH_FB(6); break;    // FAST stage A only
     case 10: ORBFE_LAUNCH_FB(10); break;  // FAST stages A + B only
+    case 26: ORBFE_LAUNCH_FB(26); break;  // A + B, stage B without its arc network (what do the ring loads cost?)
+    case 67: ORBFE_LAUNCH_FB(67); break;
+    case 195: ORBFE_LAUNCH_FB(195); break;  // the same padding with a fast-group opcode  // product kernel + 128 padding instructions per wave (is it issue-bound?)
+    case 42: ORBFE_LAUNCH_FB(42); break;  // A + B, stage B without its ring loads (what does the arithmetic cost?)
     default: ORBFE_LAUNCH_FB(3); break;
     }
 #else
