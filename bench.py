@@ -232,7 +232,8 @@ class StepRunner:
         self.s1 = self.s2 = None
         if self.cuda:
             self.s1 = torch.cuda.current_stream(device)
-            self.s2 = torch.cuda.Stream(device) if self.nbuf == 2 else self.s1
+            # BENCH_S2_PRIORITY: experiment knob (-1 = high priority for the matcher's stream); measured, no gain
+            self.s2 = torch.cuda.Stream(device, priority=int(os.environ.get("BENCH_S2_PRIORITY", "0"))) if self.nbuf == 2 else self.s1
         self.count = 0
         self.match_events = []
 
@@ -511,6 +512,9 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency block")
     ap.add_argument("--latency-calls", type=int, default=200)
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--split", type=int, default=1,
+                    help="extract the batch as this many sub-batches, each on its own handle and HIP stream, staggered by the order of "
+                         "their launches (the FAST kernel of one sub-batch beside the latency-bound kernels of the next)")
     ap.add_argument("--no-match", action="store_true", help="extract only")
     ap.add_argument("--no-overlap", action="store_true", help="match on the extraction stream (no 2-stream pipelining)")
     ap.add_argument("--lib", default=None, help="load this build of liborbfe instead (tools/: the timing-only ablation build)")
@@ -592,9 +596,28 @@ def main():
         gather = a.gather if a.gather != "auto" else ("full" if scaling == "strong" else "counts")
     state = {"gray": d_gray, "mps": None, "mpd": None}
 
+    n_split = max(1, min(a.split, B))
+    sub = [(k * B // n_split, (k + 1) * B // n_split) for k in range(n_split)]
+    sub_ex = [ex] if n_split == 1 else [orbfe.ORBextractor(*cfg, device=local_rank, max_batch=hi - lo) for lo, hi in sub]
+    sub_streams = [torch.cuda.Stream(dev) for _ in sub] if n_split > 1 else []
+    sub_events = [torch.cuda.Event() for _ in sub] if n_split > 1 else []
+    fork_event = torch.cuda.Event() if n_split > 1 else None
+
     def extract_fn(b, fs):
-        ex.extract_batch_device(state["gray"][fs].data_ptr(), W * H, W, B, b["kp"].data_ptr(), b["desc"].data_ptr(),
-                                b["n"].data_ptr(), b["per"].data_ptr(), runner.s1.cuda_stream)
+        if n_split == 1:
+            ex.extract_batch_device(state["gray"][fs].data_ptr(), W * H, W, B, b["kp"].data_ptr(), b["desc"].data_ptr(),
+                                    b["n"].data_ptr(), b["per"].data_ptr(), runner.s1.cuda_stream)
+            return
+        fork_event.record(runner.s1)
+        nl = ex.nlevels
+        for (lo, hi), e, st, ev in zip(sub, sub_ex, sub_streams, sub_events):
+            st.wait_event(fork_event)
+            e.extract_batch_device(state["gray"][fs].data_ptr() + lo * W * H, W * H, W, hi - lo, b["kp"].data_ptr() + lo * cap * 24,
+                                   b["desc"].data_ptr() + lo * cap * 32, b["n"].data_ptr() + lo * 4, b["per"].data_ptr() + lo * nl * 4,
+                                   st.cuda_stream)
+            ev.record(st)
+        for ev in sub_events:
+            runner.s1.wait_event(ev)
 
     def match_fn(b, fs):
         matcher.SearchByProjection_batch_device(B, b["kp"].data_ptr(), b["desc"].data_ptr(), b["n"].data_ptr(), cap,
@@ -712,7 +735,8 @@ def main():
                                             "results stay on the GPU that made them",
                                   "none": "none"}[gather],
                        "gather_bytes_per_step": runner.gather_bytes_per_step(),
-                       "streams": "extract(step i+1) || match(step i), double-buffered outputs" if runner.nbuf == 2 else "single stream"},
+                       "streams": ("extract(step i+1) || match(step i), double-buffered outputs" if runner.nbuf == 2 else "single stream") +
+                                  ("" if n_split == 1 else "; extraction in %d sub-batches on their own handles and streams" % n_split)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
                          "traffic": prof.get("hbm_bytes_per_launch") if prof else None,

@@ -281,8 +281,7 @@ __device__ __forceinline__ uint32_t maxi16(uint32_t a, uint32_t b)  // signed
 }
 
 // max over the sixteen 9-arcs of the arc minimum of ONE pixel's ring p[0..15] (values 0..255): the same prefix / suffix
-// scheme as arc_extreme above, 42 v_min_u16 + 15 v_max_u16.  The dark polarity goes through the same network on the
-// inverted ring (255 - p): v - min over arcs of the arc maximum == (max over arcs of the arc minimum of 255 - p) - (255 - v).
+// scheme as arc_extreme above, 42 v_min_u16 + 15 v_max_u16.
 __device__ __forceinline__ uint32_t arc_max_of_min(const uint32_t (&p)[16])
 {
     uint32_t S[16], Pf[16];
@@ -312,6 +311,39 @@ __device__ __forceinline__ uint32_t arc_max_of_min(const uint32_t (&p)[16])
     for (int st = 8; st >= 1; st >>= 1)
 #pragma unroll
         for (int k = 0; k < st; k++) a[k] = max16(a[k], a[k + st]);
+    return a[0];
+}
+
+// the dark polarity: min over the sixteen 9-arcs of the arc maximum (the same scheme with min / max exchanged)
+__device__ __forceinline__ uint32_t arc_min_of_max(const uint32_t (&p)[16])
+{
+    uint32_t S[16], Pf[16];
+    S[7] = p[7];
+    S[15] = p[15];
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+        S[k] = max16(p[k], S[k + 1]);
+        S[k + 8] = max16(p[k + 8], S[k + 9]);
+    }
+    Pf[0] = p[0];
+    Pf[8] = p[8];
+#pragma unroll
+    for (int k = 1; k < 7; k++) {
+        Pf[k] = max16(p[k], Pf[k - 1]);
+        Pf[k + 8] = max16(p[k + 8], Pf[k + 7]);
+    }
+    Pf[7] = S[0];
+    Pf[15] = S[8];
+    uint32_t a[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        a[k] = max16(S[k], Pf[k + 8]);
+        a[k + 8] = max16(S[k + 8], Pf[k]);
+    }
+#pragma unroll
+    for (int st = 8; st >= 1; st >>= 1)
+#pragma unroll
+        for (int k = 0; k < st; k++) a[k] = min16(a[k], a[k + st]);
     return a[0];
 }
 
@@ -371,11 +403,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     // barrier (after stage A) separates its last read from the first corner-queue write
     static_assert(sizeof(uint16_t) * kScH * kScW <= sizeof(uint32_t) * (kTmpH / 2) * kFastTW, "corner queue must fit the blur buffer");
     uint16_t* const sQB = reinterpret_cast<uint16_t*>(&sTmp[0][0]);
-    __shared__ uint32_t sQ[4];  // entries of queue A by wave 0 / wave 1, corner-queue entries, entries of sBoth
-    // pixels of stage B that need BOTH polarities (their dark pass runs in the main sweep, the bright one in a second,
-    // dense sweep over this list); entries beyond the capacity are finished inside the main sweep instead
-    constexpr int kBothCap = 256;
-    __shared__ uint16_t sBoth[kBothCap];
+    __shared__ uint32_t sQ[3];  // entries of queue A by wave 0 / wave 1, corner-queue entries
 
     const int f = blockIdx.x;
     const int tile = blockIdx.y;
@@ -405,7 +433,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     if (tid < 4) sCnt[tid] = 0;
-    if (tid < 4) sQ[tid] = 0;
+    if (tid < 3) sQ[tid] = 0;
     if (tid < kFastTH) sRow[tid] = 0;
 
     // ---- stage the 72 x 40 tile (origin x0-4, y0-4).  Thread -> fixed dword column c4 (18 per row) and
@@ -642,6 +670,11 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
 
     if constexpr ((MODE & 2) != 0) {
     __syncthreads();
+    if constexpr ((MODE & 512) != 0) {  // timing experiment: what do two more block barriers cost?
+        __syncthreads();
+        asm volatile("s_nop 0" ::: "memory");
+        __syncthreads();
+    }
     if constexpr ((MODE & 64) != 0) {
         // timing experiment (ablation build only): 128 independent packed instructions per lane on every wave.  If the kernel
         // is bound by vector issue its time grows by what they cost on a saturated SIMD; if it is bound by the waves' own
@@ -659,37 +692,23 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         if ((d[0] ^ d[1] ^ d[2] ^ d[3] ^ d[4] ^ d[5] ^ d[6] ^ d[7]) == 0x12345u) sCnt[0] = 1;
     }
     // ---- stage B: segment test + corner score, one queued pixel per lane; corners -> score map + corner queue.
-    //      Only ONE polarity is evaluated per pixel: a dark corner needs the dark compass test, a bright corner the bright
-    //      one, so a pixel whose dark compass test passes is scored on the inverted ring (255 - p: the same network,
-    //      arc_max_of_min) and every other pixel on the ring itself.  A pixel that passes BOTH compass tests (two compass
-    //      neighbours brighter, the two opposite ones darker: ~3 % of the queue on the bench stream, i.e. some lane of
-    //      almost every wave) is scored dark here and goes to the block's list sBoth, which a second, dense sweep scores
-    //      bright -- at most one of the two can be a corner, so each sweep simply records the corners it finds ----
+    //      hi = (max over the sixteen 9-arcs of the arc minimum) - v and lo = v - (min over the arcs of the arc maximum) are
+    //      the largest margins by which a bright / dark 9-arc clears the centre: the pixel is a corner at threshold th iff
+    //      max(hi, lo) > th (the segment test of Fast_gpu.cu:222-267) and max(hi, lo) - 1 is the score the reference finds
+    //      by binary search (:193-216).  Both polarities for every pixel: scoring only the polarity whose compass test
+    //      passed (inverted ring through one network) was built and measured -- 26 % of the queue passes BOTH compass
+    //      tests on the bench stream (diagonal edges), and the second sweep + barrier they need cost more than the second
+    //      network (fast_blur 1.27 vs 1.20 ms, profiles/r03_ab_experiments.json) ----
     if constexpr ((MODE & 4) == 0) {
         const int n0 = __builtin_amdgcn_readfirstlane((int)sQ[0]), n1 = __builtin_amdgcn_readfirstlane((int)sQ[1]);
         const int nA = n0 + n1;
         const uint8_t* img = &sImg[0][0];
         const uint32_t scoreLds = (uint32_t)(uintptr_t)&sScore[0][0] - (uint32_t)kScoreOfs, qbLds = (uint32_t)(uintptr_t)&sQB[0];
-        const uint32_t bothLds = (uint32_t)(uintptr_t)&sBoth[0];
         constexpr uint32_t kIdle = (uint32_t)(20 * kImgW + 36);  // an interior position: lanes without a pixel read valid LDS
-        uint32_t kFF = 0xffu;
-        asm("" : "+v"(kFF));
         // ring position k <-> (dy, dx): 0:(3,0) 1:(3,1) 2:(2,2) 3:(1,3) 4:(0,3) 5:(-1,3) 6:(-2,2) 7:(-3,1) 8:(-3,0)
         // 9:(-3,-1) 10:(-2,-2) 11:(-1,-3) 12:(0,-3) 13:(1,-3) 14:(2,-2) 15:(3,-1)
         constexpr int ro[16] = {3 * kImgW,      3 * kImgW + 1,  2 * kImgW + 2,  kImgW + 3,  3,  -kImgW + 3, -2 * kImgW + 2, -3 * kImgW + 1,
                                 -3 * kImgW,     -3 * kImgW - 1, -2 * kImgW - 2, -kImgW - 3, -3, kImgW - 3,  2 * kImgW - 2,  3 * kImgW - 1};
-        // corners of the lanes in `mc`: score - 1 into the score map, the pixel into the corner queue (one reservation per wave)
-        auto record = [&](unsigned long long mc, uint32_t e, uint32_t margin) {
-            masked_lds_write_b8(mc, scoreLds + e, sub16(margin, 1u));
-            const uint32_t nc = (uint32_t)__popcll(mc);
-            if (nc) {  // wave-uniform
-                uint32_t qb = 0;
-                if (lane == 0) qb = lds_add_rtn(&sQ[2], nc);
-                qb = __builtin_amdgcn_readfirstlane(qb);
-                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, 0u));
-                masked_lds_write_b16(mc, qbLds + 2u * (qb + rk), e);
-            }
-        };
 #pragma unroll 1
         for (int i0 = wv * 64; i0 < nA; i0 += 256) {   // wave-uniform trip count
             const int i = i0 + lane;
@@ -706,63 +725,28 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
 #pragma unroll
                 for (int k = 0; k < 16; k++) p[k] = pc[ro[k]];
             }
-            // compass margins of both polarities (the tests stage A merged): which network does this pixel need?
-            const uint32_t bm = sub16(min16(max16(p[0], p[8]), max16(p[4], p[12])), v);
-            const uint32_t dm = sub16(v, max16(min16(p[0], p[8]), min16(p[4], p[12])));
-            const unsigned long long mAct = mask_lt_i32((uint32_t)i, nA);
-            const unsigned long long mDark = mask_th_i16(minTh, dm);
-            unsigned long long mBoth = mDark & mask_th_i16(minTh, bm) & mAct;
-            const uint32_t inv = select_by_mask(mDark, kFF, 0u);
-            uint32_t q[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) q[k] = p[k] ^ inv;
-            const uint32_t vi = v ^ inv;
-            // margin by which the best 9-arc clears the centre: corner at threshold th iff margin > th (the segment test of
-            // Fast_gpu.cu:222-267), and margin - 1 is the score the reference finds by binary search (:193-216)
             uint32_t margin;
-            if constexpr ((MODE & 16) != 0) {  // timing experiment: no arc network
-                uint32_t acc = q[0];
+            if constexpr ((MODE & 16) != 0) {  // timing experiment: no arc networks
+                uint32_t acc = p[0];
 #pragma unroll
-                for (int k = 1; k < 16; k++) acc ^= q[k];
-                margin = sub16(acc & 0xffu, vi);
+                for (int k = 1; k < 16; k++) acc ^= p[k];
+                margin = sub16(acc & 0xffu, v);
             } else {
-                margin = sub16(arc_max_of_min(q), vi);
+                margin = maxi16(sub16(arc_max_of_min(p), v), sub16(v, arc_min_of_max(p)));
             }
-            if (mBoth != 0) {  // wave-uniform: hand the pixels over to the bright sweep
-                const uint32_t nb = (uint32_t)__popcll(mBoth);
-                uint32_t bb = 0;
-                if (lane == 0) bb = lds_add_rtn(&sQ[3], nb);
-                bb = __builtin_amdgcn_readfirstlane(bb);
-                const uint32_t pos = bb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mBoth >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mBoth, 0u));
-                const unsigned long long mFit = mBoth & mask_le_u32(pos, kBothCap - 1);
-                masked_lds_write_b16(mFit, bothLds + 2u * pos, e);
-                mBoth &= ~mFit;
-                if (mBoth != 0) {  // list full (only on contrived images): finish these pixels here -- the max of both polarities is exact
-                    uint32_t r[16];
-#pragma unroll
-                    for (int k = 0; k < 16; k++) r[k] = q[k] ^ kFF;
-                    margin = select_by_mask(mBoth, maxi16(margin, sub16(arc_max_of_min(r), vi ^ kFF)), margin);  // listed lanes keep the dark margin
-                }
+            // corners of the wave: score - 1 into the score map, the pixel into the corner queue (one reservation per wave)
+            const unsigned long long mc = mask_lt_i32((uint32_t)i, nA) & mask_th_i16(minTh, margin);
+            masked_lds_write_b8(mc, scoreLds + e, sub16(margin, 1u));
+            const uint32_t nc = (uint32_t)__popcll(mc);
+            if (nc) {  // wave-uniform
+                uint32_t qb = 0;
+                if (lane == 0) qb = lds_add_rtn(&sQ[2], nc);
+                qb = __builtin_amdgcn_readfirstlane(qb);
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, 0u));
+                masked_lds_write_b16(mc, qbLds + 2u * (qb + rk), e);
             }
-            record(mAct & mask_th_i16(minTh, margin), e, margin);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the masked LDS stores above are not counted by the compiler
-        __syncthreads();
-        // second sweep: the bright polarity of the pixels that passed both compass tests
-        const int nBoth = min((int)sQ[3], kBothCap);
-#pragma unroll 1
-        for (int i0 = wv * 64; i0 < nBoth; i0 += 256) {   // wave-uniform; usually one pass of wave 0
-            const int i = i0 + lane;
-            uint32_t e = kIdle;
-            if (i < nBoth) e = sBoth[i];
-            const uint8_t* pc = img + e;
-            uint32_t p[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) p[k] = pc[ro[k]];
-            const uint32_t margin = sub16(arc_max_of_min(p), (uint32_t)pc[0]);
-            record(mask_lt_i32((uint32_t)i, nBoth) & mask_th_i16(minTh, margin), e, margin);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
     const int nB = (MODE & 8) ? 0 : (int)sQ[2];
@@ -828,7 +812,8 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const uint32_t nTile = sCnt[0];
     if (tid == 0) {
         uint32_t base = 0;
-        if (nTile) base = atomicAdd(&cnt[kCntCand], nTile);
+        if constexpr ((MODE & 256) != 0) base = (uint32_t)tile * 8u;  // timing experiment: no returning atomic (results wrong)
+        else if (nTile) base = atomicAdd(&cnt[kCntCand], nTile);
         if (sCnt[1]) atomicAdd(&cnt[kCntHigh], sCnt[1]);
         if (sCnt[2]) atomicAdd(&cnt[kCntPreLow], sCnt[2]);
         if (sCnt[3]) atomicAdd(&cnt[kCntPreHigh], sCnt[3]);
@@ -867,7 +852,7 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
     // RESULTS ARE WRONG unless it is 3.  The shipped library does not contain these variants and reads no variable.
     static const int mode = [] {
         const char* e = getenv("ORBFE_FAST_MODE");
-        return e ? atoi(e) & 255 : 3;
+        return e ? atoi(e) & 1023 : 3;
     }();
     switch (mode) {
     case 0: ORBFE_LAUNCH_FB(0); break;
@@ -877,7 +862,9 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
     case 10: ORBFE_LAUNCH_FB(10); break;  // FAST stages A + B only
     case 26: ORBFE_LAUNCH_FB(26); break;  // A + B, stage B without its arc network (what do the ring loads cost?)
     case 67: ORBFE_LAUNCH_FB(67); break;
-    case 195: ORBFE_LAUNCH_FB(195); break;  // the same padding with a fast-group opcode  // product kernel + 128 padding instructions per wave (is it issue-bound?)
+    case 195: ORBFE_LAUNCH_FB(195); break;
+    case 259: ORBFE_LAUNCH_FB(259); break;
+    case 515: ORBFE_LAUNCH_FB(515); break;  // product kernel + two extra block barriers  // product kernel without the returning atomicAdd of the candidate reservation  // the same padding with a fast-group opcode  // product kernel + 128 padding instructions per wave (is it issue-bound?)
     case 42: ORBFE_LAUNCH_FB(42); break;  // A + B, stage B without its ring loads (what does the arithmetic cost?)
     default: ORBFE_LAUNCH_FB(3); break;
     }
