@@ -722,6 +722,8 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
 #pragma unroll
                 for (int k = 0; k < 16; k++) p[k] = v + (uint32_t)((k * 37) & 63);
             } else {
+                // (seven unaligned 8-byte reads per pixel instead of these sixteen byte reads were measured: fast_blur 2.5 ms
+                // against 1.2 -- misaligned wide LDS reads are split by the hardware; profiles/r03_ab_experiments.json)
 #pragma unroll
                 for (int k = 0; k < 16; k++) p[k] = pc[ro[k]];
             }
