@@ -2,7 +2,7 @@
 # SQ counters of the projection-matcher kernels (bench workload, matcher not overlapped)
 out=gpurun_out/pmc_match; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap > $out/a.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-io --no-latency --no-overlap > $out/a.log 2>&1
 python3 - <<'PY'
 import csv, glob
 from collections import defaultdict

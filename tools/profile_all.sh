@@ -7,7 +7,7 @@
 # Usage: tools/profile_all.sh <tag> <git-head> [bench args...]
 set -e
 tag=${1:?tag}; head=${2:-unknown}; shift; shift || true
-args="${@:---steps 5 --warmup 2 --no-cpu-baseline}"
+args="${@:---steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-latency}"
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -16,7 +16,7 @@ for r in rows:
     n = r['Name'].replace('void ', '').replace('orbfe::proj::', '').replace('orbfe::', '').replace('(anonymous namespace)::', '')
     n = re.sub(r'\((orbfe|unsigned|int|PipelineDesc|ProjArgs).*', '', n)
     out.append("%-48s calls %4s avg %9.4f ms min %8.4f max %8.4f sd %7.4f" % (n[:48], r['Calls'], float(r['AverageNs']) / 1e6, float(r['MinNs']) / 1e6, float(r['MaxNs']) / 1e6, float(r['StdDev']) / 1e6))
-txt = ("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-io --no-overlap "
+txt = ("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-io --no-latency --no-overlap "
        "(matcher after the extraction on one stream: kernel times without contention), git %s\n" % sys.argv[2]) + "\n".join(out[:9]) + "\n"
 open(sys.argv[3], 'w').write(txt)
 print(txt)
