@@ -1,0 +1,71 @@
+"""bench.py end to end on the GPU at toy sizes: the JSON line the driver parses must carry every contracted field
+(metric / value / n_gpus / roofline / cpu_baseline / latency / config.gather_bytes_per_step ...), in every mode the docs
+name: default, --images DIR, C4 strong scaling with --emulate-world, --force-gather (a 1-rank RCCL group)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(args, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contracted_fields(built):
+    d = run_bench(["--steps", "3", "--warmup", "1", "--batch", "48", "--cpu-seconds", "1", "--cpu-threads", "0", "--latency-calls", "20",
+                   "--frame-sets", "2"])
+    assert d["unit"] == "frames/s" and d["value"] > 1000 and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u8" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and "752x480" in d["metric"] and abs(d["ms_per_step"] - 48 * 1e3 / d["value"]) < 1e-6 * d["ms_per_step"] + 1e-9
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"] == "fast_nms_blur"
+    assert set(r["stage_ms_per_step"]) >= {"pyramid_resize", "fast_nms_blur", "quadtree", "orient_brief", "total", "match_projection"}
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1 and c["unit"] == "frames/s"
+    lat = d["latency"]
+    for k in ("extract_pageable_ms", "extract_pinned_ms", "extract_oracle_ms", "match_projection_ms", "match_projection_oracle_ms",
+              "prepare_and_extract_pinned_ms", "prepare_and_extract_oracle_ms"):
+        assert lat[k] > 0, k
+    assert lat["extract_pinned_ms"] < lat["extract_oracle_ms"]
+    cfg = d["config"]
+    assert cfg["frames_per_step"] == 48 and cfg["gather"] == "none" and cfg["gather_bytes_per_step"] == 0 and "workload" in cfg
+    assert d["value_host_io"] > 0 and d["value_host_io_pageable"] > 0
+
+
+def test_images_directory_mode(built, tmp_path):
+    from PIL import Image
+    from orbfe import synth
+    for i, f in enumerate(synth.stream(752, 480, 6, index0=77)):
+        Image.fromarray(f).save(tmp_path / ("%04d.pgm" % i))
+    d = run_bench(["--steps", "2", "--warmup", "1", "--batch", "16", "--frame-sets", "1", "--images", str(tmp_path), "--no-cpu-baseline",
+                   "--no-host-io", "--no-latency"])
+    assert d["data"].startswith("images: 6 files of") and d["value"] > 1000
+    assert d["config"]["mean_keypoints_per_frame"] > 900  # the files went through the extractor (the stream fills its budget)
+
+
+def test_strong_scaling_emulation_and_one_rank_gather(built):
+    e = run_bench(["--workload", "batched_1280x720", "--emulate-world", "8", "--steps", "2", "--warmup", "1", "--frame-sets", "1",
+                   "--no-cpu-baseline", "--no-host-io", "--no-latency"])
+    assert e["scaling"] == "strong" and e["n_gpus"] == 1 and e["config"]["frames_per_step"] == 64 and e["config"]["gather"] == "none"
+    assert e["emulate_world"]["world"] == 8 and abs(e["emulate_world"]["predicted_value_at_world"] - 8 * e["value"]) < 1e-6 * e["value"] * 8
+    g = run_bench(["--steps", "2", "--warmup", "1", "--batch", "32", "--frame-sets", "1", "--force-gather", "--no-cpu-baseline",
+                   "--no-host-io", "--no-latency"])
+    assert g["n_gpus"] == 1 and g["config"]["gather"].startswith("rccl all_gather of the per-frame") and g["config"]["gather_bytes_per_step"] == 32 * 8
+    f = run_bench(["--steps", "2", "--warmup", "1", "--batch", "32", "--frame-sets", "1", "--force-gather", "--gather", "full",
+                   "--no-cpu-baseline", "--no-host-io", "--no-latency"])
+    cap = 1000 + 3 * 8
+    assert f["config"]["gather_bytes_per_step"] == 32 * (cap * 60 + 4)
