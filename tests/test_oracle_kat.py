@@ -1,6 +1,7 @@
 """Pins for the CPU oracle (no GPU): the data pins the reference text provides plus
 independent restatements in Python of the pieces the oracle implements in C."""
 import hashlib
+import math
 import json
 import os
 import re
@@ -337,6 +338,87 @@ def test_orientation_and_brief_reflect_border():
     assert abs(O.ic_angle(grad, 32, 24)) < 1e-3
     assert abs(O.ic_angle(grad[:, ::-1].copy(), 32, 24) - 180) < 1e-3
     assert abs(O.ic_angle(grad.T[:64, :48].copy(), 24, 32) - 90) < 1e-3 if False else True
+
+
+def _pattern():
+    """the 256 x 4 learned pairs from the data table (its SHA-256 is pinned against the reference text above)"""
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "brief_pattern.inc")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    v = np.array([int(t) for t in re.findall(r"-?\d+", txt)], np.int64)
+    assert v.size == 1024
+    return v.reshape(256, 2, 2)  # pair, point (first / second), (x, y)
+
+
+UMAX = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+
+def py_ic_angle(img, x, y):
+    """IC_Angle_kernel (src/cuda/Angle_gpu.cu:26-80) restated on Python integers + a binary64 atan2: the centre row
+    contributes u * I(y, x+u) for |u| <= 15, rows +-v contribute over |u| <= u_max[v]; degrees in [0, 360)."""
+    im = img.astype(np.int64)
+    m10 = sum(u * im[y, x + u] for u in range(-15, 16))
+    m01 = 0
+    for v in range(1, 16):
+        d = UMAX[v]
+        plus, minus = im[y + v, x - d:x + d + 1], im[y - v, x - d:x + d + 1]
+        u = np.arange(-d, d + 1)
+        m10 += int((u * (plus + minus)).sum())
+        m01 += v * int((plus - minus).sum())
+    a = math.degrees(math.atan2(float(m01), float(m10)))
+    return a + 360.0 if a < 0 else a, (m01, m10)
+
+
+def py_brief(img, x, y, angle_deg, pat):
+    """calcOrb_kernel / getOrbValue (src/cuda/Orb_gpu.cu:311-350) restated in binary64: byte t, bit j compares pattern
+    pair 8t + j (points 16t + 2j and 16t + 2j + 1); sample = image(y + rn(px*b + py*a), x + rn(px*a - py*b)),
+    a = cos, b = sin of the angle; rn = round half to even.  Returns (descriptor, smallest distance of any rotated
+    coordinate from a rounding boundary)."""
+    r = math.radians(angle_deg)
+    a, b = math.cos(r), math.sin(r)
+    desc = np.zeros(32, np.uint8)
+    margin = 1.0
+    for t in range(32):
+        val = 0
+        for j in range(8):
+            pix = []
+            for k in range(2):
+                px, py = pat[8 * t + j, k]
+                rr, cc = px * b + py * a, px * a - py * b
+                margin = min(margin, abs(abs(rr - math.floor(rr)) - 0.5), abs(abs(cc - math.floor(cc)) - 0.5))
+                pix.append(int(img[y + int(np.rint(rr)), x + int(np.rint(cc))]))
+            val |= (pix[0] < pix[1]) << j
+        desc[t] = val
+    return desc, margin
+
+
+def test_orientation_and_brief_equal_an_independent_restatement():
+    """The oracle's orientation and descriptor against binary64 restatements of the reference kernels on interior
+    keypoints of three image classes: the integer moments must reproduce the angle to 1e-3 degrees, and the descriptor
+    must be IDENTICAL whenever no rotated sample coordinate lies within 1e-4 of a rounding boundary (elsewhere binary32
+    and binary64 may round to different pixels): pins the pattern indexing, the bit order, the rotation's signs and
+    round-half-even of the oracle -- which the GPU parity tests then carry over to the HIP path."""
+    pat = _pattern()
+    checked = 0
+    for kind, seed in (("scene", 3), ("noise", 1), ("pink", 2)):
+        img = synth.frame(160, 120, seed) if kind == "scene" else synth.hostile(kind, 160, 120, seed)
+        blur = O.gauss5(img)
+        rng = np.random.default_rng(seed)
+        for _ in range(60):
+            x, y = int(rng.integers(20, 140)), int(rng.integers(20, 100))
+            ang = O.ic_angle(img, x, y)
+            ref, (m01, m10) = py_ic_angle(img, x, y)
+            if m01 == 0 and m10 == 0:
+                continue
+            d = abs(ang - ref)
+            assert min(d, 360.0 - d) < 1e-3, (kind, x, y, ang, ref)
+            got = O.brief(blur, x, y, ang)
+            exp, margin = py_brief(blur, x, y, float(ang), pat)
+            if margin > 1e-4:
+                assert np.array_equal(got, exp), (kind, x, y, ang)
+                checked += 1
+            else:  # a sample sits on a rounding boundary: at most the pairs that touch it may flip
+                assert int(np.unpackbits(got ^ exp).sum()) <= 4, (kind, x, y, ang)
+    assert checked > 120
 
 
 def test_extract_end_to_end_invariants():
