@@ -421,6 +421,98 @@ def test_orientation_and_brief_equal_an_independent_restatement():
     assert checked > 120
 
 
+def np_resize(src, dw, dh):
+    """S1 resize restated with numpy integers: corner aligned, Q11 weights, far neighbour clamped, one rounding"""
+    sh, sw = src.shape
+    x, y = np.arange(dw, dtype=np.int64), np.arange(dh, dtype=np.int64)
+    x1, rx = (x * sw) // dw, (x * sw) % dw
+    y1, ry = (y * sh) // dh, (y * sh) % dh
+    wx, wy = (rx * 2048 + dw // 2) // dw, (ry * 2048 + dh // 2) // dh
+    x2, y2 = np.minimum(x1 + 1, sw - 1), np.minimum(y1 + 1, sh - 1)
+    s = src.astype(np.int64)
+    a, b, c, d = s[np.ix_(y1, x1)], s[np.ix_(y1, x2)], s[np.ix_(y2, x1)], s[np.ix_(y2, x2)]
+    wx, wy = wx[None, :], wy[:, None]
+    v = (a * (2048 - wx) + b * wx) * (2048 - wy) + (c * (2048 - wx) + d * wx) * wy
+    return ((v + (1 << 21)) >> 22).astype(np.uint8)
+
+
+def np_gauss5(img):
+    """S1 Gaussian restated: taps 22 62 88 62 22, REFLECT_101, unrounded row pass, one rounding after the column pass"""
+    k = np.array([22, 62, 88, 62, 22], np.int64)
+    p = np.pad(img.astype(np.int64), 2, mode="reflect")
+    h, w = img.shape
+    rows = sum(k[i] * p[:, i:i + w] for i in range(5))
+    cols = sum(k[i] * rows[i:i + h, :] for i in range(5))
+    return ((cols + 32768) >> 16).astype(np.uint8)
+
+
+def np_detect(img, th, max_kp):
+    """GpuFast::detect (Fast_gpu.cu:354-395) restated with numpy: score map of the region 6 <= x <= w-6, 6 <= y <= h-6,
+    the first max_kp PRE-NMS corners in raster order (S2b), strict 3x3 NMS against the full score map.
+    -> (xy [n,2], response [n])"""
+    h, w = img.shape
+    im = img.astype(np.int64)
+    d = np.stack([np.roll(np.roll(im, -dy, 0), -dx, 1) - im for dy, dx in RING])  # d[k][y, x] = I(y+dy, x+dx) - I(y, x)
+    idx = (np.arange(16)[:, None] + np.arange(9)[None, :]) % 16
+    bright = d[idx].min(axis=1).max(axis=0)
+    dark = (-d)[idx].min(axis=1).max(axis=0)
+    m = np.maximum(bright, dark)
+    score = np.where(m > th, m - 1, 0)
+    valid = np.zeros_like(score, bool)
+    valid[6:h - 5, 6:w - 5] = True
+    score = np.where(valid, score, 0)
+    ys, xs = np.nonzero(score > 0)  # raster order
+    ys, xs = ys[:max_kp], xs[:max_kp]
+    pad = np.pad(score, 1)
+    nb = np.stack([pad[1 + dy:1 + dy + h, 1 + dx:1 + dx + w] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if dx or dy]).max(axis=0)
+    keep = score[ys, xs] > nb[ys, xs]
+    return np.stack([xs[keep], ys[keep]], 1), score[ys, xs][keep]
+
+
+@pytest.mark.parametrize("nfast", [20000, 700, 260])
+def test_whole_extractor_equals_an_independent_python_pipeline(nfast):
+    """ORBextractor::extractFeatures (ORBextractor.cc:432-585) end to end on a small image, every stage from a second,
+    independent restatement: numpy pyramid (S1), numpy FAST + NMS + pre-NMS cap, the two-threshold retry with its
+    unsigned difference and the tail trim (:449-482), the Python std::list choreography of DistributeOctTree, best point
+    per node (first wins), KeyPoint fill (size = int(31 * invScale), level-major order); orientation and descriptor come
+    from the oracle's own functions, which the test above pins separately.  With nFast 20000 no cap acts, 700 trims the
+    low list, 260 also cuts the pre-NMS list."""
+    args = (150, nfast, 1.2, 3, 20, 7, 128, 96)
+    e = O.Extractor(*args)
+    img = synth.hostile("pink", 128, 96, 4)
+    kp, desc, per = e.extract(img)
+    out_kp, out_desc = [], []
+    level = img
+    for l in range(3):
+        if l:
+            level = np_resize(level, int(e.levelW[l]), int(e.levelH[l]))
+        blur = np_gauss5(level)
+        assert np.array_equal(level, e.level_image(l, False)) and np.array_equal(blur, e.level_image(l, True))
+        h, w = level.shape
+        xy_h, r_h = np_detect(level, 20, nfast)
+        xy, resp = xy_h, r_h
+        diff = (nfast - len(xy_h)) & 0xFFFFFFFF  # unsigned int arithmetic (:463)
+        if diff > 0.25 * nfast:
+            xy_l, r_l = np_detect(level, 7, nfast)
+            n_low = len(xy_l)
+            if len(xy_h) + n_low > nfast:
+                n_low -= len(xy_h) + n_low - nfast
+            xy, resp = np.concatenate([xy_h, xy_l[:n_low]]), np.concatenate([r_h, r_l[:n_low]])
+        if len(xy) == 0:
+            continue
+        sel = py_distribute([tuple(map(int, p)) for p in xy], [int(r) for r in resp], w, h, int(e.featuresPerLevel[l]))
+        for k in sel:
+            x, y = int(xy[k][0]), int(xy[k][1])
+            out_kp.append((np.float32(x), np.float32(y), int(resp[k]), np.float32(int(31 * e.invScaleFactors[l])), l,
+                           O.ic_angle(level, x, y)))
+            out_desc.append(O.brief(blur, x, y, out_kp[-1][5]))
+    ref = np.array(out_kp, dtype=O.KP_DTYPE)
+    assert len(ref) == len(kp) and len(kp) > 100
+    for f in ("x", "y", "response", "size", "octave"):
+        assert np.array_equal(ref[f], kp[f]), f
+    assert ref["angle"].tobytes() == kp["angle"].tobytes() and np.array_equal(np.array(out_desc), desc)
+
+
 def test_extract_end_to_end_invariants():
     e = O.Extractor(300, 20000, 1.2, 4, 20, 7, 320, 240)
     img = synth.frame(320, 240, 1)
