@@ -469,19 +469,21 @@ def np_detect(img, th, max_kp):
     return np.stack([xs[keep], ys[keep]], 1), score[ys, xs][keep]
 
 
-@pytest.mark.parametrize("nfast", [20000, 700, 260])
-def test_whole_extractor_equals_an_independent_python_pipeline(nfast):
+@pytest.mark.parametrize("kind,nfast", [("pink", 20000), ("pink", 700), ("pink", 260), ("saltpepper", 600)])
+def test_whole_extractor_equals_an_independent_python_pipeline(kind, nfast):
     """ORBextractor::extractFeatures (ORBextractor.cc:432-585) end to end on a small image, every stage from a second,
     independent restatement: numpy pyramid (S1), numpy FAST + NMS + pre-NMS cap, the two-threshold retry with its
     unsigned difference and the tail trim (:449-482), the Python std::list choreography of DistributeOctTree, best point
     per node (first wins), KeyPoint fill (size = int(31 * invScale), level-major order); orientation and descriptor come
-    from the oracle's own functions, which the test above pins separately.  With nFast 20000 no cap acts, 700 trims the
-    low list, 260 also cuts the pre-NMS list."""
+    from the oracle's own functions, which the test above pins separately.  With nFast 20000 no cap acts; 700 and 260 cut
+    the pre-NMS lists of both passes (Fast_gpu.cu:278-281); on the salt-and-pepper frame (every corner survives the NMS)
+    600 makes high + low exceed the budget, so the low list's tail is trimmed (:470-473)."""
     args = (150, nfast, 1.2, 3, 20, 7, 128, 96)
     e = O.Extractor(*args)
-    img = synth.hostile("pink", 128, 96, 4)
+    img = synth.hostile(kind, 128, 96, 4)
     kp, desc, per = e.extract(img)
     out_kp, out_desc = [], []
+    trimmed = False
     level = img
     for l in range(3):
         if l:
@@ -497,6 +499,7 @@ def test_whole_extractor_equals_an_independent_python_pipeline(nfast):
             n_low = len(xy_l)
             if len(xy_h) + n_low > nfast:
                 n_low -= len(xy_h) + n_low - nfast
+                trimmed = True
             xy, resp = np.concatenate([xy_h, xy_l[:n_low]]), np.concatenate([r_h, r_l[:n_low]])
         if len(xy) == 0:
             continue
@@ -507,6 +510,7 @@ def test_whole_extractor_equals_an_independent_python_pipeline(nfast):
                            O.ic_angle(level, x, y)))
             out_desc.append(O.brief(blur, x, y, out_kp[-1][5]))
     ref = np.array(out_kp, dtype=O.KP_DTYPE)
+    assert trimmed == (kind == "saltpepper")
     assert len(ref) == len(kp) and len(kp) > 100
     for f in ("x", "y", "response", "size", "octave"):
         assert np.array_equal(ref[f], kp[f]), f
