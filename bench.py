@@ -483,8 +483,8 @@ def launcher_selftest(a, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU in weak-scaling mode")
     ap.add_argument("--workload", default="euroc_752x480", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
