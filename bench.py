@@ -703,8 +703,9 @@ def main():
                      "lds_per_wave": prof.get("lds_per_wave"), "waves": prof["waves_per_launch"],
                      # waves x valu / (1024 SIMDs x clk / 2 x t): the guide's 2-cycle wave64 VALU rate ...
                      "issue_frac": wi / (SIMDS * CLK_HZ / 2.0 * dom_ms * 1e-3),
-                     # ... and against the rate tools/valu_rate.hip measures for the integer / packed instructions this
-                     # kernel is made of (4 cycles per wave64 instruction per SIMD; profiles/r02_valu_rate.txt)
+                     # ... and against the rate tools/valu_rate.hip measures for packed / 32-bit min-max instructions (4 cycles per
+                     # wave64 instruction per SIMD; two thirds of this kernel's instructions are of the 2.3-cycle group:
+                     # profiles/r03_valu_rate.txt)
                      "issue_frac_at_measured_4_cycles": wi / (SIMDS * CLK_HZ / 4.0 * dom_ms * 1e-3)}
         out = {
             "metric": "frames/sec ORB %s, %dx%d %d-level %d-feat; bit-exact kp/desc" % (
@@ -743,8 +744,10 @@ def main():
                          "profiles_head": prof.get("git_head") if prof else None,
                          "profile_file": prof.get("file") if prof else None,
                          "issue": issue,
-                         "limiter": "VALU issue: the kernel's integer min/max, packed-16 and byte-permute instructions cost 4 cycles per "
-                                    "wave64 instruction per SIMD (profiles/r02_valu_rate.txt), see roofline.issue",
+                         "limiter": "VALU issue, with the LDS byte gathers of the corner-score stage as the second limit: packed-16, dot, "
+                                    "permute and 32-bit min/max instructions cost ~4.2 cycles per wave64 instruction per SIMD, the 16-bit "
+                                    "min/max/sub and add/and/or/xor forms the FAST stages run on ~2.3 (profiles/r03_valu_rate.txt); 128 extra "
+                                    "packed instructions per wave cost 81 % of their saturated price (profiles/r03_ab_experiments.json)",
                          "input_set_bytes": int(n_sets * B * W * H),
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
                          "extract_pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
