@@ -21,15 +21,16 @@
 // Tile: 64 x 32 pixels per 256-thread block; the level tile + 4-px halo (3 ring + 1 NMS; the blur
 // needs 2) is staged ONCE in LDS with dword loads and feeds both computations.
 //
-// The kernel is bound by VALU issue (tools/valu_rate.hip: the integer min / max / perm / packed-16 instructions cost
-// 4 cycles per wave64 instruction per SIMD on gfx950, and the kernel runs at ~90 % of that), so every stage is
-// written for the fewest vector instructions per pixel:
-//   stage A  compass pre-test on every position with PACKED 16-bit arithmetic: a lane owns 4 columns x 5 rows,
-//            reads the tile as dwords and unpacks column pairs with v_perm_b32, so each v_pk_min/max_u16 tests
-//            two pixels (two waves, 126 lanes); survivors (~20 % of the positions) go to an LDS queue;
-//   stage B  segment test + corner score of TWO queued pixels per lane, again packed: the sixteen 9-arcs of
-//            both polarities by prefix / suffix minima over the ring halves (57 packed instructions per polarity
-//            for two pixels instead of 40 three-input ones per pixel and polarity);
+// The kernel is bound by vector-instruction issue, with the LDS byte gathers of stage B as the second limit
+// (DESIGN.md section 4.2).  gfx950 retires the plain 16-bit VOP2 integer instructions (v_min_u16 / v_max_u16 / v_sub_u16
+// / v_max_i16) and add / and / or / xor at ~2.3 cycles per wave64 instruction, every packed v_pk_* form, v_perm, v_dot*,
+// v_mbcnt and all 32-bit min / max at ~4.2 (tools/valu_rate.hip, profiles/r03_valu_rate.txt): ONE pixel per lane on
+// the fast instructions costs what two pixels per lane cost on the packed ones, without the packing around them.
+//   stage A  compass pre-test on every position: lane = column, a wave walks 17 rows down that column with a seven-row
+//            register window (three byte loads + nine fast instructions per pixel); survivors (~20 % of the
+//            positions) go to an LDS queue through a hand-scheduled compaction step;
+//   stage B  segment test + corner score of one queued pixel per lane: the sixteen 9-arcs of both polarities by
+//            prefix / suffix minima over the ring halves (42 v_min_u16 + 15 v_max_u16 per polarity);
 //   stage C  NMS + compaction over the dense corner queue.
 // Candidate order in HBM is not deterministic (one atomicAdd per block reserves the slots) -- every
 // consumer is order-independent: it uses the raster key (y, x) carried in the word (S2b).
@@ -54,65 +55,6 @@ constexpr int kQCap = 2304;                               // queue A slots (>= 6
 static_assert(kQCap >= kScH * kScW && kQCap % 2 == 0, "stage A geometry");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef short i16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max_u(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, (i16x2)(__builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b)));
-}
-
-// Both corner margins of TWO pixels at once (one per 16-bit half): p[k] = ring value k of pixel A | of pixel B << 16,
-// v = their centres.  hi = (max over the sixteen 9-arcs of the arc minimum) - v and lo = v - (min over the arcs of the
-// arc maximum) are the largest margins by which a bright / dark 9-arc clears the centre; the pixel is a corner at
-// threshold th iff max(hi, lo) > th (the segment test of Fast_gpu.cu:222-267) and max(hi, lo) - 1 is the score the
-// reference finds by binary search (:193-216).  Arc k = ring positions k..k+8.  With S[k] = min(p[k..7]),
-// S'[k] = min(p[k..15]), P[k] = min(p[8..k]), P'[k] = min(p[0..k]):  arc k = min(S[k], P[k+8]) for k < 8 and
-// min(S'[k], P'[k-8]) for k >= 8 -- 26 + 16 two-input minima, 15 maxima.
-template <bool DARK>
-__device__ __forceinline__ uint32_t arc_extreme(const uint32_t (&p)[16])
-{
-    auto inner = [](uint32_t a, uint32_t b) { return DARK ? pk_max_u(a, b) : pk_min_u(a, b); };
-    auto outer = [](uint32_t a, uint32_t b) { return DARK ? pk_min_u(a, b) : pk_max_u(a, b); };
-    uint32_t S[16], Pf[16];
-    S[7] = p[7];
-    S[15] = p[15];
-#pragma unroll
-    for (int k = 6; k >= 0; k--) {
-        S[k] = inner(p[k], S[k + 1]);
-        S[k + 8] = inner(p[k + 8], S[k + 9]);
-    }
-    Pf[0] = p[0];
-    Pf[8] = p[8];
-#pragma unroll
-    for (int k = 1; k < 7; k++) {
-        Pf[k] = inner(p[k], Pf[k - 1]);
-        Pf[k + 8] = inner(p[k + 8], Pf[k + 7]);
-    }
-    Pf[7] = S[0];    // min of the whole half
-    Pf[15] = S[8];
-    uint32_t a[16];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        a[k] = inner(S[k], Pf[k + 8]);
-        a[k + 8] = inner(S[k + 8], Pf[k]);
-    }
-#pragma unroll
-    for (int st = 8; st >= 1; st >>= 1)
-#pragma unroll
-        for (int k = 0; k < st; k++) a[k] = outer(a[k], a[k + st]);
-    return a[0];
-}
 
 
 // lane mask of (unsigned)x <= bound / of a > b, straight from the compare (a ballot of a combined predicate costs hipcc a
@@ -162,28 +104,10 @@ __device__ __forceinline__ unsigned long long mask_lt_i32(uint32_t a, int b, boo
     else asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
     return m;
 }
-// lane masks of th < (signed 16-bit low / high half of m)
-__device__ __forceinline__ unsigned long long mask_th_lo(int th, uint32_t m)
-{
-    unsigned long long r;
-    asm("v_cmp_lt_i16_e64 %0, %1, %2" : "=s"(r) : "s"(th), "v"(m));
-    return r;
-}
-__device__ __forceinline__ unsigned long long mask_th_hi(int th, uint32_t m)
-{
-    unsigned long long r;
-    asm("v_cmp_lt_i32_sdwa %0, %1, sext(%2) src0_sel:DWORD src1_sel:WORD_1" : "=s"(r) : "s"(th), "v"(m));
-    return r;
-}
 __device__ __forceinline__ void masked_lds_write_b8(unsigned long long mask, uint32_t addr, uint32_t v)
 {
     unsigned long long save;
     asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "scc", "memory");
-}
-__device__ __forceinline__ void masked_lds_write_b8_hi(unsigned long long mask, uint32_t addr, uint32_t v)  // bits 23..16 of v
-{
-    unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b8_d16_hi %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "scc", "memory");
 }
 __device__ __forceinline__ void masked_lds_write_b16(unsigned long long mask, uint32_t addr, uint32_t v)
 {
@@ -203,49 +127,6 @@ __device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* addr, uint32_t v)
     uint32_t old;
     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"((uint32_t)(uintptr_t)addr), "v"(v) : "memory");
     return old;
-}
-
-// One compaction step of stage A, hand-scheduled (hipcc turns the same source into 9 vector instructions per step:
-// it rebuilds the ballot through v_cndmask + v_cmp and masks the 16-bit half before comparing it).  The lanes whose
-// 16-bit half of the margin m (HIGH: bits 31..16) exceeds th and that are valid in both lane masks append their half of
-// entryPair (the staged byte offsets of the two positions) to the queue
-// at byte address qNext + rank * step; returns how many did.  EXEC is narrowed and restored inside the statement.
-template <bool HIGH>
-__device__ __forceinline__ int queue_slot(uint32_t m, int th, unsigned long long colMask, unsigned long long rowMask, uint32_t entryPair,
-                                          int stepV, int qNext)
-{
-    unsigned long long save;
-    uint32_t tmp;
-    int cnt;
-    if constexpr (HIGH)
-        asm volatile("v_cmp_lt_i32_sdwa vcc, %9, sext(%3) src0_sel:DWORD src1_sel:WORD_1\n\t"
-                     "s_and_b64 vcc, vcc, %4\n\t"
-                     "s_and_b64 vcc, vcc, %5\n\t"
-                     "s_and_saveexec_b64 %0, vcc\n\t"
-                     "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
-                     "v_mad_i32_i24 %1, %1, %7, %8\n\t"
-                     "ds_write_b16_d16_hi %1, %6\n\t"
-                     "s_mov_b64 exec, %0\n\t"
-                     "s_bcnt1_i32_b64 %2, vcc"
-                     : "=&s"(save), "=&v"(tmp), "=s"(cnt)
-                     : "v"(m), "s"(colMask), "s"(rowMask), "v"(entryPair), "v"(stepV), "s"(qNext), "s"(th)
-                     : "vcc", "scc", "memory");
-    else
-        asm volatile("v_cmp_lt_i16_e32 vcc, %9, %3\n\t"
-                     "s_and_b64 vcc, vcc, %4\n\t"
-                     "s_and_b64 vcc, vcc, %5\n\t"
-                     "s_and_saveexec_b64 %0, vcc\n\t"
-                     "v_mbcnt_lo_u32_b32 %1, vcc_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %1, vcc_hi, %1\n\t"
-                     "v_mad_i32_i24 %1, %1, %7, %8\n\t"
-                     "ds_write_b16 %1, %6\n\t"
-                     "s_mov_b64 exec, %0\n\t"
-                     "s_bcnt1_i32_b64 %2, vcc"
-                     : "=&s"(save), "=&v"(tmp), "=s"(cnt)
-                     : "v"(m), "s"(colMask), "s"(rowMask), "v"(entryPair), "v"(stepV), "s"(qNext), "s"(th)
-                     : "vcc", "scc", "memory");
-    return cnt;
 }
 
 // ---- round 3: the 16-bit VOP2 instructions below belong to the fast group of this chip (tools/valu_rate.hip,
@@ -280,8 +161,10 @@ __device__ __forceinline__ uint32_t maxi16(uint32_t a, uint32_t b)  // signed
     return r;
 }
 
-// max over the sixteen 9-arcs of the arc minimum of ONE pixel's ring p[0..15] (values 0..255): the same prefix / suffix
-// scheme as arc_extreme above, 42 v_min_u16 + 15 v_max_u16.
+// max over the sixteen 9-arcs of the arc minimum of ONE pixel's ring p[0..15] (values 0..255).  Arc k = ring positions
+// k..k+8.  With S[k] = min(p[k..7]), S'[k] = min(p[k..15]), P[k] = min(p[8..k]), P'[k] = min(p[0..k]):  arc k =
+// min(S[k], P[k+8]) for k < 8 and min(S'[k], P'[k-8]) for k >= 8 -- 26 + 16 two-input minima, then 15 maxima
+// (42 v_min_u16 + 15 v_max_u16).
 __device__ __forceinline__ uint32_t arc_max_of_min(const uint32_t (&p)[16])
 {
     uint32_t S[16], Pf[16];
@@ -355,8 +238,10 @@ __device__ __forceinline__ unsigned long long mask_th_i16(int th, uint32_t m)
     return r;
 }
 
-// One compaction step of stage A (one pixel per lane): the lanes of `mask` whose signed 16-bit margin m exceeds th append
-// `entry` (the staged byte offset of their pixel) to the queue at byte address qNext + rank * step; returns how many did.
+// One compaction step of stage A (one pixel per lane), hand-scheduled (hipcc turns the same source into 9 vector
+// instructions per step: it rebuilds the ballot through v_cndmask + v_cmp): the lanes of `mask` whose signed 16-bit margin
+// m exceeds th append `entry` (the staged byte offset of their pixel) to the queue at byte address qNext + rank * step;
+// returns how many did.  EXEC is narrowed and restored inside the statement.
 __device__ __forceinline__ int queue_slot1(uint32_t m, int th, unsigned long long mask, uint32_t entry, int stepV, int qNext)
 {
     unsigned long long save;
