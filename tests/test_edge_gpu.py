@@ -60,6 +60,42 @@ def test_padded_pitch_and_frame_stride(built):
     assert got[0].tobytes() == kp_r.tobytes() and np.array_equal(got[1], desc_r)
 
 
+@pytest.mark.parametrize("pitch_extra,base_off", [(3, 0), (0, 1), (5, 3), (1, 2)])
+def test_unaligned_device_input(built, pitch_extra, base_off):
+    """Level 0 handed over with a pitch or a base address that is not a multiple of 4 (a cropped view of a larger image):
+    the kernels leave the dword paths (byte staging in the FAST kernel, the tile resize kernel for level 1, unstaged patch
+    reads in orient_brief) and must give the same bytes."""
+    import torch
+    import orbfe
+    W, H, B = 321, 243, 2
+    args = (300, 20000, 1.2, 4, 20, 7, W, H)
+    pitch = W + pitch_extra
+    stride = pitch * H + 7
+    ex = orbfe.ORBextractor(*args, device=0, max_batch=B)
+    ref = O.Extractor(*args)
+    buf = np.random.default_rng(1).integers(0, 256, base_off + B * stride + 16, dtype=np.uint8)  # garbage around the frames
+    ims = [synth.frame(W, H, 50 + b) for b in range(B)]
+    for b in range(B):
+        v = buf[base_off + b * stride: base_off + b * stride + H * pitch].reshape(H, pitch)
+        v[:, :W] = ims[b]
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(buf).to(dev)
+    cap = ex.cap
+    d_kp = torch.zeros(B * cap * 24, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d_in.data_ptr() + base_off, stride, pitch, B, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), None, None)
+    torch.cuda.synchronize(dev)
+    n = d_n.cpu().numpy()
+    kp = d_kp.cpu().numpy().view(orbfe.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+    for b in range(B):
+        kp_r, desc_r, _ = ref.extract(ims[b])
+        assert n[b] == len(kp_r) and kp[b, :n[b]].tobytes() == kp_r.tobytes() and np.array_equal(desc[b, :n[b]], desc_r), b
+        for l in range(4):
+            assert np.array_equal(ex.pyramid_level(l, True, frame=b), ref.level_image(l, True)), (b, l)
+
+
 def test_matcher_empty_and_invalid_inputs(built):
     import orbfe
     ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=1)
