@@ -96,6 +96,26 @@ def test_unaligned_device_input(built, pitch_extra, base_off):
             assert np.array_equal(ex.pyramid_level(l, True, frame=b), ref.level_image(l, True)), (b, l)
 
 
+@pytest.mark.parametrize("W,H", [(3840, 2160), (4095, 2303)])
+def test_frames_at_the_size_limit(built, W, H):
+    """4K frames and the largest level the packed candidate words allow (x, y < 4096): 130 x 72 FAST
+    tiles in level 0, 32-bit byte offsets of ~9.4 MB per frame, 5000 features, one frame and a batch of two."""
+    import orbfe
+    args = (5000, 400000, 1.2, 8, 20, 7, W, H)
+    ex = orbfe.ORBextractor(*args, device=0, max_batch=2)
+    ref = O.Extractor(*args)
+    ims = [synth.frame(W, H, 3), synth.hostile("pink", W, H, 1)]
+    res = ex.extract_batch(ims)
+    for im, (kp, desc, per) in zip(ims, res):
+        kp_r, desc_r, per_r = ref.extract(im)
+        assert len(kp) == len(kp_r) > 4000 and np.array_equal(per, per_r)
+        assert kp.tobytes() == kp_r.tobytes() and np.array_equal(desc, desc_r)
+    # one past the limit is refused at create
+    with pytest.raises(orbfe.OrbfeError) as e:
+        orbfe.ORBextractor(5000, 400000, 1.2, 8, 20, 7, 4097, 2303, device=0, max_batch=1)
+    assert e.value.code in (1, 2)
+
+
 def test_matcher_empty_and_invalid_inputs(built):
     import orbfe
     ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=1)
