@@ -33,7 +33,6 @@ import contextlib
 import glob
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -314,37 +313,31 @@ def host_io_rate(ex, frames, slot_frames, rounds, pinned):
     return done / dt
 
 
-def _free_port():
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-    sk.close()
-    return port
-
-
 def launch_ranks(n, argv):
     """`bench.py --gpus N` started as ONE process: start N ranks (one per GPU) through torch.distributed.run on
     127.0.0.1 and relay rank 0's JSON line.  The parent never initialises the GPU (no torch.cuda call, no HIP call): the
-    ranks are fresh child processes.  Returns the exit code of the launch."""
+    ranks are fresh child processes.  torchrun picks the rendezvous port itself (--standalone: c10d store on port 0), so
+    two launches started together cannot race for one.  Returns the exit code of the launch."""
+    import collections
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL (the host driver supports nothing else)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node=%d" % n, os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, text=True)
     line = None
+    tail = collections.deque(maxlen=30)  # what the ranks said last, for the error message of a failed launch
     for out in proc.stdout:
         t = out.strip()
         if t.startswith("{") and '"metric"' in t:
             line = t
         else:
+            tail.append(out)
             sys.stderr.write(out)  # anything else the ranks print is not the result line
     rc = proc.wait()
-    if rc != 0:
-        sys.stderr.write("bench.py: the %d-rank launch failed with exit code %d\n" % (n, rc))
-        return rc
-    if line is None:
-        sys.stderr.write("bench.py: the %d-rank launch printed no result line\n" % n)
-        return 3
+    if rc != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank launch %s; last output of the ranks:\n%s" % (
+            n, "failed with exit code %d" % rc if rc != 0 else "printed no result line", "".join(tail)))
+        return rc if rc != 0 else 3
     print(line, flush=True)
     return 0
 
@@ -525,6 +518,9 @@ def main():
         # started as one process: become the launcher of N ranks BEFORE anything touches the GPU
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
+    # both launch forms (ours above, the driver's torch.distributed.run) run the ranks with dmabuf IPC: set before the
+    # first torch.cuda / HIP call of this process
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -671,10 +667,13 @@ def main():
         dt = time.perf_counter() - t0
         stage_ms, ncalls = ex.stage_ms()
         ex.set_stage_timing(False)
+        state["rank_dt"] = (dt, dt)
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            # MAX over ranks is the job's time; MIN beside it makes an imbalance between the GPUs visible in the one line
+            t = torch.tensor([dt, -dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt = float(t[0].item())
+            state["rank_dt"] = (-float(t[1].item()), dt)
         return dt, stage_ms, ncalls
 
     dt, stage_ms, ncalls = timed_run(a.steps, a.warmup)
@@ -716,6 +715,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
+            "ms_per_step_ranks": {"min": state["rank_dt"][0] / a.steps * 1e3, "max": state["rank_dt"][1] / a.steps * 1e3},
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,

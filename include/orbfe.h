@@ -334,10 +334,12 @@ int orbfe_project_map_points_device(orbfe_handle *h, const orbfe_frustum *frustu
                                     float *d_proj_xr, void *stream);
 
 /* what ORBmatcher::SearchForTriangulation derives from the two key-frame poses (src/ORBmatcher.cc:448-465).
- * ABI note: the library reads the WHOLE struct as declared here (it grew a camera-model tail in round 2 and carries
- * no size / version field): zero-initialise it (`orbfe_tri_params p = {0};`) and rebuild callers against this header --
- * a caller compiled against the shorter round-1 layout would hand over a short buffer. */
+ * ABI: the block is versioned by its size.  struct_size must hold sizeof(orbfe_tri_params) of the header the CALLER was
+ * compiled against (`orbfe_tri_params p = ORBFE_TRI_PARAMS_INIT;` zero-initialises the rest); the library refuses any
+ * other value with ORBFE_ERR_INVALID_ARG instead of reading past a shorter block (the struct grew a camera-model tail in
+ * round 2). */
 typedef struct orbfe_tri_params {
+    int struct_size;        /* sizeof(orbfe_tri_params) at the caller's compile time */
     float f12[9];           /* F12 = K1^-T [t12]x R12 K2^-1, row-major: the matrix Pinhole::epipolarConstrain
                              * rebuilds for every pair (src/CameraModels/Pinhole.cpp:106-109) */
     float ep_x, ep_y;       /* epipole: pKF2->mpCamera->project(T2w * Cw) (:451-454) */
@@ -356,6 +358,7 @@ typedef struct orbfe_tri_params {
     float level_sigma2_1[ORBFE_MAX_LEVELS]; /* pKF1->mvLevelSigma2 (sigmaLevel of the first view; unc is 1.0, :603) */
     int kf1_has_camera2;    /* pKF1->mpCamera2 is set: the epipole gate (:551) is skipped */
 } orbfe_tri_params;
+#define ORBFE_TRI_PARAMS_INIT {(int)sizeof(orbfe_tri_params)}
 
 /* replaces ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse,
  * checkOrientation) (src/ORBmatcher.cc:441-676; caller src/LocalMapping.cc:488), one pinhole camera per key

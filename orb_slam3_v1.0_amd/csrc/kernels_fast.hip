@@ -230,7 +230,7 @@ __device__ __forceinline__ uint32_t arc_min_of_max(const uint32_t (&p)[16])
     return a[0];
 }
 
-// lane mask of th < (signed 16-bit) m, through VCC (the e32 compare)
+// lane mask of th < (signed 16-bit) m, into an SGPR pair (the e64 compare; VCC stays free)
 __device__ __forceinline__ unsigned long long mask_th_i16(int th, uint32_t m)
 {
     unsigned long long r;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                                                         uint32_t* __restrict__ tileRows)
 {
     __shared__ uint32_t sRow[kFastTH];  // pre-NMS corners per tile row: low-pass count | high-pass count << 16
-    __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH + 1][kImgW];  // + 1 row: stage A reads row 40 for positions it masks
+    __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH + 1][kImgW];  // + 1 spare row (the column walk of stage A reads at most row 39; kept so the arrays behind keep their offsets)
     __shared__ __attribute__((aligned(16))) uint32_t sTmp[kTmpH / 2][kFastTW];  // row pairs of horizontal sums
     __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH + 1][kScPitch];
     __shared__ uint32_t sCand[kMaxTileCand];
@@ -748,10 +748,10 @@ void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineD
     case 6: ORBFE_LAUNCH_FB(6); break;    // FAST stage A only
     case 10: ORBFE_LAUNCH_FB(10); break;  // FAST stages A + B only
     case 26: ORBFE_LAUNCH_FB(26); break;  // A + B, stage B without its arc network (what do the ring loads cost?)
-    case 67: ORBFE_LAUNCH_FB(67); break;
-    case 195: ORBFE_LAUNCH_FB(195); break;
-    case 259: ORBFE_LAUNCH_FB(259); break;
-    case 515: ORBFE_LAUNCH_FB(515); break;  // product kernel + two extra block barriers  // product kernel without the returning atomicAdd of the candidate reservation  // the same padding with a fast-group opcode  // product kernel + 128 padding instructions per wave (is it issue-bound?)
+    case 67: ORBFE_LAUNCH_FB(67); break;    // product kernel + 128 padding instructions per wave (is it issue-bound?)
+    case 195: ORBFE_LAUNCH_FB(195); break;  // the same padding with a fast-group opcode
+    case 259: ORBFE_LAUNCH_FB(259); break;  // product kernel without the returning atomicAdd of the candidate reservation
+    case 515: ORBFE_LAUNCH_FB(515); break;  // product kernel + two extra block barriers
     case 42: ORBFE_LAUNCH_FB(42); break;  // A + B, stage B without its ring loads (what does the arithmetic cost?)
     default: ORBFE_LAUNCH_FB(3); break;
     }

@@ -409,7 +409,9 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     h->hPer = reinterpret_cast<int*>(h->hOutBlock + h->offPer);
     h->hKp = reinterpret_cast<orbfe_keypoint*>(h->hOutBlock + h->offKp);
     h->hDesc = h->hOutBlock + h->offDesc;
-    h->useGraph = getenv("ORBFE_NO_GRAPH") == nullptr;
+#ifdef ORBFE_DIAG
+    h->useGraph = getenv("ORBFE_NO_GRAPH") == nullptr;  // liborbfe_diag.so only: plain launches, e.g. under a debugger
+#endif
     CREATE_CHK(hipEventCreateWithFlags(&h->evExtract, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&h->evMatch, hipEventDisableTiming));
     h->match.busy = h->evMatch;  // the arena is not regrown while a launch still uses it
@@ -1354,6 +1356,11 @@ int orbfe_match_triangulation(orbfe_handle* h, int n_groups, const int* kf1_off,
         (n2 > 0 && (!kp2 || !desc2 || !has_mp2)))
         return ORBFE_ERR_INVALID_ARG;
     if (n_groups > 0 && ((kf1_off[n_groups] > 0 && !kf1_idx) || (kf2_off[n_groups] > 0 && !kf2_idx))) return ORBFE_ERR_INVALID_ARG;
+    if (params->struct_size != (int)sizeof(orbfe_tri_params)) {  // a caller built against another layout of the block
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->err = "orbfe_tri_params.struct_size does not match this library (rebuild the caller against include/orbfe.h)";
+        return ORBFE_ERR_INVALID_ARG;
+    }
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;

@@ -60,11 +60,15 @@ class Sim3View(C.Structure):
 
 class TriParams(C.Structure):
     """orbfe_tri_params: F12, epipole and the three flags of SearchForTriangulation."""
-    _fields_ = [("f12", C.c_float * 9), ("ep_x", C.c_float), ("ep_y", C.c_float), ("only_stereo", C.c_int),
+    _fields_ = [("struct_size", C.c_int), ("f12", C.c_float * 9), ("ep_x", C.c_float), ("ep_y", C.c_float), ("only_stereo", C.c_int),
                 ("coarse", C.c_int), ("check_orientation", C.c_int),
                 ("camera_model1", C.c_int), ("camera_model2", C.c_int), ("cam1", C.c_float * 8), ("cam2", C.c_float * 8),
                 ("kb_precision", C.c_float), ("r12", C.c_float * 9), ("t12", C.c_float * 3),
                 ("level_sigma2_1", C.c_float * 32), ("kf1_has_camera2", C.c_int)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(TriParams)
 
 
 def fill_tri_cameras(P, cameras):

@@ -181,7 +181,7 @@ int main(int argc, char** argv)
         kf->mvScaleFactors = ex.GetScaleFactors();
         kf->mvInvLevelSigma2 = ex.GetInverseScaleSigmaSquares();
         for (int i = 0; i < n; i++) kf->mFeatVec[(unsigned)(i % 50)].push_back((unsigned)i);
-        orbfe_tri_params tp{};
+        orbfe_tri_params tp = ORBFE_TRI_PARAMS_INIT;
         tp.ep_x = -1e4f; tp.ep_y = 0.f; tp.coarse = 1; tp.check_orientation = 1;
         std::vector<std::pair<size_t, size_t>> pairs;
         const int nt = KeyFrameMatcher::SearchForTriangulation(ex.handle(), kf, kf, tp, pairs,

@@ -193,6 +193,8 @@ def test_init_sequential_kernel_forced_on_small_inputs(built):
     exists only in the diagnostics build liborbfe_diag.so (`make diag`, -DORBFE_DIAG) -- the shipped library reads no such
     variable -- so this runs once in a child process that loads that build."""
     import subprocess
+    import __graft_entry__ as g
+    g.build_variant("diag")  # built on demand: build() only makes the shipped library
     env = dict(os.environ, ORBFE_INIT_SLOW="1", ORBFE_TEST_LIB="liborbfe_diag.so")
     p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "forced sequential kernel: 4 cases exact" in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
