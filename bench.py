@@ -416,6 +416,49 @@ def latency_block(cfg, device_index, frames, reps=200):
     fvo = O.make_frame_view(kp_r, desc_r, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors)
     out["match_projection_oracle_ms"] = _median_ms(lambda: O.search_by_projection(fvo, mps.view(O.MP_DTYPE), mpd, None, MATCH_TH, MATCH_NN), 15, 2)
     out["match_projection_map_points"] = N_MAP_POINTS
+    # the whole per-frame chain of the tracking thread (src/Tracking.cc:152-173,1059-1115): ExtractORB -> isInFrustum over the
+    # local map -> SearchByProjection, as three host-synchronous calls and as ONE submission (orbfe_track_frame: one graph)
+    import frustum_scenarios as FS
+    Fp, Fo = orbfe.Frustum(), O.Frustum()
+    snake = {k: k for k in ("rcw", "tcw", "twc", "min_x", "max_x", "min_y", "max_y", "fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4",
+                            "mbf", "log_scale_factor", "n_levels", "camera_model")}
+    camel = dict(snake, min_x="minX", max_x="maxX", min_y="minY", max_y="maxY", log_scale_factor="logScaleFactor", n_levels="nLevels",
+                 camera_model="cameraModel")
+    v = FS.fill_frustum(Fp, snake, W=float(W), H=float(H), n_levels=ex1.nlevels, scale=cfg[2], seed=21)
+    FS.fill_frustum(Fo, camel, W=float(W), H=float(H), n_levels=ex1.nlevels, scale=cfg[2], seed=21)
+    wpts, wdesc = FS.world_points_on_keypoints(kp, desc, v, N_MAP_POINTS, np.random.default_rng(12), ex1.nlevels, orbfe.WP_DTYPE)
+    trk = orbfe.FrameTracker(ex1, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H))
+    out["project_map_points_ms"] = _median_ms(lambda: m1.isInFrustum_batch(Fp, wpts), reps)
+    mps3, _ = m1.isInFrustum_batch(Fp, wpts)
+
+    def three_calls():
+        it["i"] += 1
+        k, d = ex1.extractFeatures(pinned[it["i"] % len(pinned)])
+        mp, _ = m1.isInFrustum_batch(Fp, wpts)
+        f = orbfe.make_frame_view(k, d, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ex1.mvScaleFactor)
+        return m1.SearchByProjection(f, mp, wdesc, MATCH_TH, False, 0.0, MATCH_NN, None)
+
+    def fused(src):
+        def fn():
+            it["i"] += 1
+            return trk.TrackFrame(src[it["i"] % len(src)], Fp, wpts, wdesc, MATCH_TH, MATCH_NN)
+        return fn
+
+    out["three_calls_ms"] = _median_ms(three_calls, reps)
+    out["track_frame_ms"] = _median_ms(fused(pinned), reps)
+    out["track_frame_pageable_ms"] = _median_ms(fused(pageable), reps)
+    got = trk.TrackFrame(pageable[0], Fp, wpts, wdesc, MATCH_TH, MATCH_NN)
+    out["track_frame_matches"] = int(got["nmatches"])
+
+    def oracle_chain():
+        k, d, _ = ref.extract(pageable[0])
+        mp, _ = O.is_in_frustum(Fo, wpts.view(O.WP_DTYPE))
+        f = O.make_frame_view(k, d, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors)
+        return O.search_by_projection(f, mp, wdesc, None, MATCH_TH, MATCH_NN)
+
+    n_o, match_o = oracle_chain()
+    out["track_frame_equals_oracle"] = bool(n_o == got["nmatches"] and np.array_equal(match_o, got["match"]))
+    out["track_frame_oracle_ms"] = _median_ms(oracle_chain, 10, 1)
     # node-side chain at the node's own configuration (mono_inertial_node.cpp:20,59-71): 2048x1536 BGR -> 614x460 grey -> extract
     SW, SH, DW, DH = 2048, 1536, 614, 460
     pcfg = (cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], DW, DH)
@@ -432,7 +475,9 @@ def latency_block(cfg, device_index, frames, reps=200):
         refp.extract(O.prepare_image(bgr, map1, map2, DW, DH))
     out["prepare_and_extract_oracle_ms"] = _median_ms(oracle_chain, 3, 1)
     out["what"] = ("one %dx%d host frame per call through orbfe_extract (one captured hipGraph: H2D, kernels, D2H, sync); "
-                   "orbfe_match_projection with %d map points, host pointers; orbfe_prepare_and_extract %dx%d BGR -> %dx%d; "
+                   "orbfe_match_projection with %d map points, host pointers; three_calls = orbfe_extract + orbfe_project_map_points + "
+                   "orbfe_match_projection back to back (three host synchronisations), track_frame = the same chain through "
+                   "orbfe_track_frame (one graph, one synchronisation); orbfe_prepare_and_extract %dx%d BGR -> %dx%d; "
                    "`*_oracle_ms` = the single-thread C oracle on the same call" % (W, H, N_MAP_POINTS, SW, SH, DW, DH))
     prep.close()
     return out

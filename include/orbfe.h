@@ -333,6 +333,48 @@ int orbfe_project_map_points_device(orbfe_handle *h, const orbfe_frustum *frustu
                                     const orbfe_world_point *d_points, orbfe_map_point *d_out,
                                     float *d_proj_xr, void *stream);
 
+/* -------------------------------------------------------------------------------------------
+ * The tracking thread's per-frame chain as ONE submission
+ * ---------------------------------------------------------------------------------------- */
+
+/* the frame statics and call parameters SearchByProjection reads besides the map points (src/Frame.cc:101-105,
+ * src/Tracking.cc:1108-1115); versioned by its size like orbfe_tri_params */
+typedef struct orbfe_track_params {
+    int struct_size;               /* sizeof(orbfe_track_params) at the caller's compile time */
+    int grid_cols, grid_rows;      /* mFrameGridCols / mFrameGridRows */
+    float min_x, min_y;            /* mnMinX / mnMinY */
+    float grid_inv_w, grid_inv_h;  /* mfGridElementWidthInv / mfGridElementHeightInv */
+    float th;                      /* 20 before the IMU is initialised, 40 after (src/Tracking.cc:1108-1113) */
+    float nn_ratio;                /* 0.85 / 0.75 */
+    int far_points;                /* bFarPoints */
+    float th_far_points;           /* thFarPoints */
+} orbfe_track_params;
+#define ORBFE_TRACK_PARAMS_INIT {(int)sizeof(orbfe_track_params)}
+
+/* What the tracking thread of this fork does with every frame once the IMU is initialised, in one call:
+ *   Frame::Frame -> ExtractORB -> ORBextractor::extractFeatures          (src/Tracking.cc:152-173, src/Frame.cc:178-189)
+ *   Tracking::SearchLocalPoints: isInFrustum for every local map point   (src/Tracking.cc:1059-1077, src/Frame.cc:272-333)
+ *   ORBmatcher::SearchByProjection(mCurrentFrame, mvpLocalMapPoints, ...) (src/Tracking.cc:1108-1115)
+ * The pose that isInFrustum needs does not depend on the frame's features here: TrackWithMotionModel is the IMU
+ * prediction alone (src/Tracking.cc:908-923, PredictStateIMU :293), and the local map comes from the LAST frame's
+ * matches (:1190), so image, predicted pose and local map points are all known when the frame arrives.
+ * Equivalent to orbfe_extract + orbfe_project_map_points + orbfe_match_projection (frame view = the fresh keypoints
+ * with the grid of `tp` and the extractor's own mvScaleFactors; init_obs == NULL: mvpMapPoints is empty at that point),
+ * bit for bit -- but as ONE captured hipGraph: the host frame and one block [frustum | points | descriptors] go up,
+ * memset + extraction kernels + frustum kernel + three matcher kernels run back to back with no host in between, ONE
+ * result block comes back, one host synchronisation.
+ * gray / pitch as orbfe_extract; points / mp_desc: n_points local map points (HOST pointers; mp_desc n_points x 32);
+ * frustum->n_levels must not exceed the extractor's level count.
+ * kp_out / desc_out / n_out / per_level_counts as orbfe_extract; mp_out (n_points records, may be NULL) and proj_xr_out
+ * (may be NULL) as orbfe_project_map_points; match_out (orbfe_max_keypoints() ints; the first *n_out are meaningful)
+ * and n_matches as orbfe_match_projection.  A frame without keypoints gives *n_out == 0 and *n_matches == 0.
+ * Graphs are cached per (n_points rounded up to a bucket, input pitch, tp): a steady stream replays one graph. */
+int orbfe_track_frame(orbfe_handle *h, const uint8_t *gray, int pitch, const orbfe_frustum *frustum,
+                      const orbfe_track_params *tp, int n_points, const orbfe_world_point *points,
+                      const uint8_t *mp_desc, orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out,
+                      int *per_level_counts, orbfe_map_point *mp_out, float *proj_xr_out, int *match_out,
+                      int *n_matches);
+
 /* what ORBmatcher::SearchForTriangulation derives from the two key-frame poses (src/ORBmatcher.cc:448-465).
  * ABI: the block is versioned by its size.  struct_size must hold sizeof(orbfe_tri_params) of the header the CALLER was
  * compiled against (`orbfe_tri_params p = ORBFE_TRI_PARAMS_INIT;` zero-initialises the rest); the library refuses any

@@ -582,6 +582,83 @@ struct LocalPointProjector {
     }
 };
 
+// The tracking thread's per-frame chain as ONE submission (orbfe_track_frame): what Tracking::GrabImageMonocular does with
+// a frame once the IMU is initialised -- Frame::Frame -> ExtractORB (src/Tracking.cc:152-173, src/Frame.cc:178-189), then
+// Track() -> TrackWithMotionModel (IMU prediction only, :908-923) -> TrackLocalMap -> SearchLocalPoints: the isInFrustum
+// loop (:1059-1077) and ORBmatcher::SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, false, thFarPoints, nnRatio)
+// (:1108-1115).  The caller builds `frustum` from the PREDICTED pose (it does not depend on the frame's features) and
+// passes the local map of UpdateLocalMap (:930).  On return `F` carries the fresh keypoints and descriptors and the
+// matches in mvpMapPoints, the map points carry their mTrack* fields (LocalPointProjector's contract), *nToMatch is the
+// reference's counter.  `F` needs: mNumKeypoints, mvKeysUn, mvpMapPoints, the grid statics (as SearchByProjection above);
+// the descriptor rows go to the frame through setDesc(F, rows, n) (cv::cuda::HostMem in the reference, a vector here).
+// Returns the match count, or -1 when the frame has no keypoints (the reference returns before Track(), :158-159).
+struct FrameTracker {
+    template <class FramePtr, class MapPointPtr, class DescOfMapPoint, class SetFrameDesc>
+    static int ExtractAndSearchLocalPoints(ORBextractor& extractor, const GrayImageView& im, FramePtr F, const orbfe_frustum& frustum,
+                                           long unsigned int currentFrameId, const std::vector<MapPointPtr>& vpLocalMapPoints,
+                                           const float th, const bool bFarPoints, const float thFarPoints, const float nnRatio,
+                                           DescOfMapPoint mpDesc, SetFrameDesc setDesc, int* nToMatch = nullptr)
+    {
+        orbfe_handle* h = extractor.handle();
+        const int cap = extractor.maxKeypoints();
+        const int M = (int)vpLocalMapPoints.size();
+        std::vector<orbfe_world_point> pts(M > 0 ? M : 1);
+        std::vector<uint8_t> mpd((size_t)(M > 0 ? M : 1) * 32);
+        for (int i = 0; i < M; i++) {
+            const auto& pMP = vpLocalMapPoints[i];
+            const auto P = pMP->GetWorldPos();
+            pts[i] = orbfe_world_point{P[0], P[1], P[2], pMP->mfMinDistance, pMP->mfMaxDistance, pMP->isBad() ? 1 : 0,
+                                       pMP->Observations(), pMP->mnLastFrameSeen == currentFrameId ? 1 : 0};
+            std::memcpy(&mpd[(size_t)i * 32], mpDesc(pMP), 32);
+        }
+        orbfe_track_params tp = ORBFE_TRACK_PARAMS_INIT;
+        tp.grid_cols = F->getFrameGridCols();
+        tp.grid_rows = F->getFrameGridRows();
+        tp.min_x = F->mnMinX;
+        tp.min_y = F->mnMinY;
+        tp.grid_inv_w = F->mfGridElementWidthInv;
+        tp.grid_inv_h = F->mfGridElementHeightInv;
+        tp.th = th;
+        tp.nn_ratio = nnRatio;
+        tp.far_points = bFarPoints ? 1 : 0;
+        tp.th_far_points = thFarPoints;
+        auto keys = std::make_shared<std::vector<KeyPoint>>(cap);
+        std::vector<uint8_t> desc((size_t)cap * ORBFE_DESC_BYTES);
+        std::vector<int> match(cap);
+        std::vector<orbfe_map_point> out(M > 0 ? M : 1);
+        std::vector<float> xr(M > 0 ? M : 1);
+        int n = 0, nmatches = 0;
+        orbfe_detail::check(orbfe_track_frame(h, im.data, im.pitch, &frustum, &tp, M, pts.data(), mpd.data(),
+                                              reinterpret_cast<orbfe_keypoint*>(keys->data()), desc.data(), &n, nullptr, out.data(),
+                                              xr.data(), match.data(), &nmatches), h, "orbfe_track_frame");
+        keys->resize(n);
+        F->mNumKeypoints = n;
+        F->mvKeysUn = keys;
+        setDesc(F, desc.data(), n);
+        F->mvpMapPoints.assign(n, nullptr);
+        int toMatch = 0;
+        for (int i = 0; i < M; i++) {  // what isInFrustum leaves in the map points (src/Frame.cc:274-276,319-328)
+            if (pts[i].skip || pts[i].bad) continue;
+            const auto& pMP = vpLocalMapPoints[i];
+            pMP->mbTrackInView = out[i].in_view != 0;
+            pMP->mTrackProjX = out[i].proj_x;
+            pMP->mTrackProjY = out[i].proj_y;
+            if (out[i].in_view) {
+                pMP->mTrackProjXR = xr[i];
+                pMP->mTrackDepth = out[i].track_depth;
+                pMP->mnTrackScaleLevel = out[i].level;
+                pMP->mTrackViewCos = out[i].view_cos;
+                toMatch++;
+            }
+        }
+        if (nToMatch) *nToMatch = toMatch;
+        if (n == 0) return -1;
+        for (int i = 0; i < n; i++)
+            if (match[i] >= 0) F->mvpMapPoints[i] = vpLocalMapPoints[match[i]];  // src/ORBmatcher.cc:113
+        return nmatches;
+    }
+};
+
 // ORB_SLAM3::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:29-30), the
 // part Frame::ComputeBoW / KeyFrame::ComputeBoW use (src/Frame.cc:483-495): load the text vocabulary, transform a
 // frame's descriptors into BowVector + FeatureVector.  The tree descent of every feature runs on the GPU

@@ -20,11 +20,9 @@ namespace orbfe {
 
 namespace {
 
-__global__ __launch_bounds__(256) void frustum_kernel(orbfe_frustum F, int n, const orbfe_world_point* __restrict__ pts,
-                                                      orbfe_map_point* __restrict__ out, float* __restrict__ projXR)
+__device__ __forceinline__ void frustum_point(const orbfe_frustum& F, int i, const orbfe_world_point* __restrict__ pts,
+                                              orbfe_map_point* __restrict__ out, float* __restrict__ projXR)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const orbfe_world_point p = pts[i];
     orbfe_map_point o;
     o.proj_x = -1.0f;  // :275-276
@@ -74,6 +72,25 @@ __global__ __launch_bounds__(256) void frustum_kernel(orbfe_frustum F, int n, co
     if (projXR) projXR[i] = xr;
 }
 
+__global__ __launch_bounds__(256) void frustum_kernel(orbfe_frustum F, int n, const orbfe_world_point* __restrict__ pts,
+                                                      orbfe_map_point* __restrict__ out, float* __restrict__ projXR)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) frustum_point(F, i, pts, out, projXR);
+}
+
+// the frame's pose and camera read from HBM: a captured hipGraph (orbfe_track_frame) freezes kernel arguments, so whatever
+// changes from frame to frame has to arrive through memory
+__global__ __launch_bounds__(256) void frustum_dev_kernel(const orbfe_frustum* __restrict__ dF, int n,
+                                                          const orbfe_world_point* __restrict__ pts,
+                                                          orbfe_map_point* __restrict__ out, float* __restrict__ projXR)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const orbfe_frustum F = *dF;  // block-uniform: scalar loads
+    frustum_point(F, i, pts, out, projXR);
+}
+
 }  // namespace
 
 int frustum_validate(const orbfe_frustum* F)
@@ -92,6 +109,19 @@ int frustum_launch(hipStream_t s, const orbfe_frustum* F, int n, const orbfe_wor
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         err = std::string("frustum_kernel: ") + hipGetErrorString(e);
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+int frustum_launch_dev(hipStream_t s, const orbfe_frustum* dF, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,
+                       float* dProjXR, std::string& err)
+{
+    if (n == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(frustum_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dF, n, dPts, dOut, dProjXR);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        err = std::string("frustum_dev_kernel: ") + hipGetErrorString(e);
         return ORBFE_ERR_HIP;
     }
     return ORBFE_OK;

@@ -64,5 +64,8 @@ int distinctive_run(MatchScratch& m, hipStream_t s, int nSets, const int* setOff
 int frustum_validate(const orbfe_frustum* F);
 int frustum_launch(hipStream_t s, const orbfe_frustum* F, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,
                    float* dProjXR, std::string& err);
+// the same with the frustum block resident in HBM (orbfe_track_frame: the launch is part of a captured hipGraph)
+int frustum_launch_dev(hipStream_t s, const orbfe_frustum* dF, int n, const orbfe_world_point* dPts, orbfe_map_point* dOut,
+                       float* dProjXR, std::string& err);
 
 }  // namespace orbfe

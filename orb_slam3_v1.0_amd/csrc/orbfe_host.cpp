@@ -21,6 +21,7 @@
 #include "launch.h"
 #include "match.h"
 #include "match_common.h"
+#include "match_proj.h"
 #include "prep.h"
 #include "vocab.h"
 
@@ -96,6 +97,24 @@ struct orbfe_handle {
     int lastPitch = 0, lastBatch = 0;
 
     MatchScratch match;
+
+    // orbfe_track_frame: the fused per-frame chain.  Its captured graphs hold the addresses of these blocks and of this
+    // matcher arena, so nothing else uses them and a regrow drops every graph.
+    struct TrackKey {
+        int Mb, inPitch, gridCols, gridRows, farPoints;
+        float minX, minY, invW, invH, th, nnRatio, thFar;
+    };
+    struct TrackGraph {
+        TrackKey key;
+        hipGraphExec_t exec;
+    };
+    MatchScratch trackMatch;
+    uint8_t* dTrkIn = nullptr;   // [image | frustum | points (Mb) | descriptors (Mb)]
+    uint8_t* hTrkIn = nullptr;   // pinned mirror
+    uint8_t* dTrkOut = nullptr;  // [n, status, n_matches | per-level | keypoints | descriptors | match | map-point records (Mb) | xr (Mb)]
+    uint8_t* hTrkOut = nullptr;  // pinned mirror
+    int trkCapM = 0;
+    std::vector<TrackGraph> trackGraphs;
     std::mutex mu;
     std::string err;
 
@@ -181,6 +200,13 @@ void destroy_impl(orbfe_handle* h)
     if (h->evMatch) (void)hipEventDestroy(h->evMatch);
     h->match.busy = nullptr;
     match_scratch_free(h->match);
+    for (auto& g : h->trackGraphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    match_scratch_free(h->trackMatch);
+    if (h->dTrkIn) (void)hipFree(h->dTrkIn);
+    if (h->dTrkOut) (void)hipFree(h->dTrkOut);
+    if (h->hTrkIn) (void)hipHostFree(h->hTrkIn);
+    if (h->hTrkOut) (void)hipHostFree(h->hTrkOut);
     for (auto& g : h->graphs)
         if (g.second) (void)hipGraphExecDestroy(g.second);
     void* dptrs[] = {h->dP, h->ws, h->dCand, h->dNodeOf, h->dCounters, h->dLvlKp, h->dTileRows, h->dQtScratch, h->dTabs,
@@ -717,6 +743,255 @@ int orbfe_extract(orbfe_handle* h, const uint8_t* gray, int pitch, orbfe_keypoin
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// orbfe_track_frame: extract -> isInFrustum -> SearchByProjection as one captured hipGraph (orbfe.h)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// map points per graph: rounded up so that a local map that grows by a few points replays the same graph; the padding
+// records are "bad" (isInFrustum leaves them out of view, SearchByProjection skips them), so results do not change
+int track_bucket(int M)
+{
+    int g = 256;
+    while (g * 8 <= M) g <<= 1;  // <= 8 buckets per octave
+    return std::max(g, (M + g - 1) / g * g);
+}
+
+struct TrackLayout {
+    size_t inFrame, oFr, oPts, oMpDesc, inBytes;                              // input block
+    size_t oPer, oKp, oDesc, oMatch, oMps, oXr, outBytes;                     // result block ([n, status, n_matches] at 0)
+};
+
+TrackLayout track_layout(const orbfe_handle* h, int Mb)
+{
+    TrackLayout L{};
+    const size_t cap = (size_t)h->P.kpCapFrame;
+    L.inFrame = align_up((size_t)h->dInPitch * h->prm.image_height, 256);
+    L.oFr = L.inFrame;
+    L.oPts = L.oFr + align_up(sizeof(orbfe_frustum), 256);
+    L.oMpDesc = L.oPts + (size_t)Mb * sizeof(orbfe_world_point);
+    L.inBytes = L.oMpDesc + (size_t)Mb * ORBFE_DESC_BYTES;
+    size_t off = 256;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.oPer = take((size_t)h->nLevels * sizeof(int));
+    L.oKp = take(cap * sizeof(orbfe_keypoint));
+    L.oDesc = take(cap * ORBFE_DESC_BYTES);
+    L.oMatch = take(cap * sizeof(int));
+    L.oMps = take((size_t)Mb * sizeof(orbfe_map_point));
+    L.oXr = take((size_t)Mb * sizeof(float));
+    L.outBytes = off;
+    return L;
+}
+
+void track_drop_graphs(orbfe_handle* h)
+{
+    for (auto& g : h->trackGraphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->trackGraphs.clear();
+}
+
+// (re)allocate the blocks for Mb map points; the caller holds h->mu and nothing of this path is in flight
+int track_reserve(orbfe_handle* h, int Mb)
+{
+    if (Mb <= h->trkCapM) return ORBFE_OK;
+    track_drop_graphs(h);
+    if (h->dTrkIn) (void)hipFree(h->dTrkIn);
+    if (h->dTrkOut) (void)hipFree(h->dTrkOut);
+    if (h->hTrkIn) (void)hipHostFree(h->hTrkIn);
+    if (h->hTrkOut) (void)hipHostFree(h->hTrkOut);
+    h->dTrkIn = h->dTrkOut = h->hTrkIn = h->hTrkOut = nullptr;
+    h->trkCapM = 0;
+    const int capM = Mb + Mb / 2;  // head-room: a growing local map does not reallocate (and re-capture) at every bucket
+    const TrackLayout L = track_layout(h, capM);
+    if (hipMalloc(&h->dTrkIn, L.inBytes) != hipSuccess || hipMalloc(&h->dTrkOut, L.outBytes) != hipSuccess ||
+        hipHostMalloc(&h->hTrkIn, L.inBytes) != hipSuccess || hipHostMalloc(&h->hTrkOut, L.outBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        h->err = "orbfe_track_frame: allocation of the staging blocks failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    h->trkCapM = capM;
+    return ORBFE_OK;
+}
+
+// the device side of one call, enqueued on s (directly, or under stream capture): extraction chain on the uploaded
+// frame, projection of the uploaded map points with the uploaded frustum, SearchByProjection on the fresh keypoints,
+// download of the result block
+int track_enqueue(orbfe_handle* h, const TrackLayout& L, int Mb, int inPitch, proj::ProjArgs& A, hipStream_t s)
+{
+    int* dHead = reinterpret_cast<int*>(h->dTrkOut);  // [n, status, n_matches]
+    int rc = extract_chain(h, h->dTrkIn, L.inFrame, inPitch, 1, reinterpret_cast<orbfe_keypoint*>(h->dTrkOut + L.oKp),
+                           h->dTrkOut + L.oDesc, dHead, reinterpret_cast<int*>(h->dTrkOut + L.oPer), dHead + 1, s);
+    if (rc != ORBFE_OK) return rc;
+    std::string err;
+    rc = frustum_launch_dev(s, reinterpret_cast<const orbfe_frustum*>(h->dTrkIn + L.oFr), Mb,
+                            reinterpret_cast<const orbfe_world_point*>(h->dTrkIn + L.oPts),
+                            reinterpret_cast<orbfe_map_point*>(h->dTrkOut + L.oMps), reinterpret_cast<float*>(h->dTrkOut + L.oXr), err);
+    if (rc == ORBFE_OK) rc = proj::proj_launch(s, A, err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->hTrkOut, h->dTrkOut, L.outBytes, hipMemcpyDeviceToHost, s));
+    return ORBFE_OK;
+}
+
+}  // namespace
+
+extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch, const orbfe_frustum* frustum,
+                                 const orbfe_track_params* tp, int M, const orbfe_world_point* points, const uint8_t* mp_desc,
+                                 orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, orbfe_map_point* mp_out,
+                                 float* proj_xr_out, int* match_out, int* n_matches)
+{
+    if (!h || !gray || !tp || !kp_out || !desc_out || !n_out || !match_out || !n_matches || M < 0 || (M > 0 && (!points || !mp_desc)))
+        return ORBFE_ERR_INVALID_ARG;
+    if (pitch < h->prm.image_width || pitch >= (1 << 24)) return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (tp->struct_size != (int)sizeof(orbfe_track_params)) {
+        h->err = "orbfe_track_params.struct_size does not match this library (rebuild the caller against include/orbfe.h)";
+        return ORBFE_ERR_INVALID_ARG;
+    }
+    if (tp->grid_cols < 1 || tp->grid_rows < 1 || frustum->n_levels > h->nLevels) return ORBFE_ERR_INVALID_ARG;
+    if (h->P.kpCapFrame >= (1 << 20) || tp->grid_cols > 65535 || tp->grid_rows > 32767 ||
+        (long long)tp->grid_cols * tp->grid_rows > proj::kMaxCells || M > (1 << 24))
+        return ORBFE_ERR_UNSUPPORTED;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;
+    const int cap = h->P.kpCapFrame;
+    const int Mb = track_bucket(M);
+    int rc = track_reserve(h, Mb);
+    if (rc != ORBFE_OK) return rc;
+    const TrackLayout L = track_layout(h, Mb);
+
+    // ---- matcher arguments; the arena is sized here, outside any capture ----
+    proj::ProjArgs A{};
+    A.B = 1; A.M = Mb; A.kpStride = cap;
+    A.g = proj::GridDesc{tp->grid_cols, tp->grid_rows, tp->min_x, tp->min_y, tp->grid_inv_w, tp->grid_inv_h};
+    A.th = tp->th; A.thFar = tp->th_far_points; A.nnRatio = tp->nn_ratio; A.farPoints = tp->far_points; A.bFactor = tp->th != 1.0;
+    A.kp = reinterpret_cast<const orbfe_keypoint*>(h->dTrkOut + L.oKp);
+    A.desc = h->dTrkOut + L.oDesc;
+    A.nKp = reinterpret_cast<const int*>(h->dTrkOut);
+    A.mps = reinterpret_cast<const orbfe_map_point*>(h->dTrkOut + L.oMps);
+    A.mpDesc = h->dTrkIn + L.oMpDesc;
+    A.initObs = nullptr;
+    A.scaleFactors = h->dSf; A.nLevels = nL;
+    A.matchOut = reinterpret_cast<int*>(h->dTrkOut + L.oMatch);
+    A.nMatches = reinterpret_cast<int*>(h->dTrkOut) + 2;
+    {
+        std::string err;
+        void* before = h->trackMatch.d;
+        rc = proj::proj_setup(h->trackMatch, A, Carver(), 64, err);
+        if (rc != ORBFE_OK) {
+            h->err = err;
+            return rc;
+        }
+        if (before && h->trackMatch.d != before) track_drop_graphs(h);  // the arena moved: graphs hold its old address
+    }
+
+    // ---- stage the small block [frustum | points | descriptors], padding records marked bad ----
+    memcpy(h->hTrkIn + L.oFr, frustum, sizeof(orbfe_frustum));
+    if (M) memcpy(h->hTrkIn + L.oPts, points, (size_t)M * sizeof(orbfe_world_point));
+    {
+        orbfe_world_point pad{};
+        pad.bad = 1;
+        pad.skip = 1;
+        orbfe_world_point* hp = reinterpret_cast<orbfe_world_point*>(h->hTrkIn + L.oPts);
+        for (int i = M; i < Mb; i++) hp[i] = pad;
+    }
+    if (M) memcpy(h->hTrkIn + L.oMpDesc, mp_desc, (size_t)M * ORBFE_DESC_BYTES);
+    if (Mb > M) memset(h->hTrkIn + L.oMpDesc + (size_t)M * ORBFE_DESC_BYTES, 0, (size_t)(Mb - M) * ORBFE_DESC_BYTES);
+
+    // ---- upload: pinned frames straight from the caller's buffer + the small block; pageable ones through the
+    //      pinned mirror, where frame and small block are ONE copy ----
+    bool direct = pitch <= h->dInPitch && (pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(gray) & 3u) == 0;
+    if (direct) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, gray) != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            direct = false;
+        }
+    }
+    int inPitch;
+    if (direct) {
+        inPitch = pitch;
+        HIPCHK(h, hipMemcpyAsync(h->dTrkIn, gray, (size_t)pitch * (H - 1) + (size_t)W, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->dTrkIn + L.oFr, h->hTrkIn + L.oFr, L.inBytes - L.oFr, hipMemcpyHostToDevice, s));
+    } else {
+        if ((pitch & 3) == 0 && pitch <= h->dInPitch) {  // a dword-aligned pitch is kept: the frame is one contiguous copy
+            inPitch = pitch;
+            memcpy(h->hTrkIn, gray, (size_t)pitch * (H - 1) + (size_t)W);
+        } else {
+            inPitch = h->dInPitch;
+            for (int y = 0; y < H; y++) memcpy(h->hTrkIn + (size_t)y * inPitch, gray + (size_t)y * pitch, (size_t)W);
+        }
+        HIPCHK(h, hipMemcpyAsync(h->dTrkIn, h->hTrkIn, L.inBytes, hipMemcpyHostToDevice, s));
+    }
+
+    // ---- kernels + download: replay the graph of this (bucket, pitch, parameters), capturing it first if needed ----
+    bool viaGraph = h->useGraph && !h->timing;
+    if (viaGraph) {
+        const orbfe_handle::TrackKey key{Mb, inPitch, tp->grid_cols, tp->grid_rows, tp->far_points, tp->min_x, tp->min_y,
+                                         tp->grid_inv_w, tp->grid_inv_h, tp->th, tp->nn_ratio, tp->th_far_points};
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : h->trackGraphs)
+            if (memcmp(&g.key, &key, sizeof key) == 0) exec = g.exec;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = track_enqueue(h, L, Mb, inPitch, A, s);
+            const hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (rc == ORBFE_OK && ec == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+                exec = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!exec) {
+                (void)hipGetLastError();
+                h->useGraph = false;  // plain launches for the lifetime of the handle
+                viaGraph = false;
+            } else {
+                if (h->trackGraphs.size() >= 64) track_drop_graphs(h);  // a caller cycling through parameters: bounded cache
+                h->trackGraphs.push_back({key, exec});
+            }
+        }
+        if (viaGraph) {
+            rc = scratch_acquire(h, h->extractUsed, h->extractStream, h->evExtract, s);
+            if (rc != ORBFE_OK) return rc;
+            HIPCHK(h, hipGraphLaunch(exec, s));
+            rc = extract_scratch_release(h, s);
+            if (rc != ORBFE_OK) return rc;
+            h->lastGray = h->dTrkIn;
+            h->lastStride = L.inFrame;
+            h->lastPitch = inPitch;
+            h->lastBatch = 1;
+        }
+    }
+    if (!viaGraph) {
+        rc = track_enqueue(h, L, Mb, inPitch, A, s);
+        if (rc != ORBFE_OK) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+
+    // ---- hand over ----
+    const int* head = reinterpret_cast<const int*>(h->hTrkOut);
+    if (head[1]) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "device guard flags 0x%x in orbfe_track_frame", (unsigned)head[1]);
+        h->err = buf;
+        return ORBFE_ERR_INTERNAL;
+    }
+    const int n = head[0];
+    *n_out = n;
+    *n_matches = n > 0 ? head[2] : 0;
+    memcpy(kp_out, h->hTrkOut + L.oKp, (size_t)n * sizeof(orbfe_keypoint));
+    memcpy(desc_out, h->hTrkOut + L.oDesc, (size_t)n * ORBFE_DESC_BYTES);
+    memcpy(match_out, h->hTrkOut + L.oMatch, (size_t)n * sizeof(int));
+    if (per_level) memcpy(per_level, h->hTrkOut + L.oPer, (size_t)nL * sizeof(int));
+    if (mp_out && M) memcpy(mp_out, h->hTrkOut + L.oMps, (size_t)M * sizeof(orbfe_map_point));
+    if (proj_xr_out && M) memcpy(proj_xr_out, h->hTrkOut + L.oXr, (size_t)M * sizeof(float));
+    return ORBFE_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Pipelined host-pointer extraction (orbfe.h: orbfe_stream_*)

@@ -87,6 +87,17 @@ def fill_tri_cameras(P, cameras):
     P.kf1_has_camera2 = int(cameras.get("kf1HasCamera2", 0))
 
 
+class TrackParams(C.Structure):
+    """orbfe_track_params: frame grid statics (src/Frame.cc:101-105) + the call parameters of SearchByProjection."""
+    _fields_ = [("struct_size", C.c_int), ("grid_cols", C.c_int), ("grid_rows", C.c_int), ("min_x", C.c_float),
+                ("min_y", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("th", C.c_float),
+                ("nn_ratio", C.c_float), ("far_points", C.c_int), ("th_far_points", C.c_float)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(TrackParams)
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int), ("kp", C.c_void_p), ("desc", C.c_void_p), ("grid_cols", C.c_int),
                 ("grid_rows", C.c_int), ("min_x", C.c_float), ("min_y", C.c_float),
@@ -104,7 +115,7 @@ SYMBOLS = [
     "orbfe_prep_create", "orbfe_prep_destroy", "orbfe_prepare_image", "orbfe_prepare_image_device", "orbfe_prepare_and_extract",
     "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_right", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
     "orbfe_get_device_status", "orbfe_stream_create", "orbfe_stream_destroy", "orbfe_stream_submit", "orbfe_stream_collect",
-    "orbfe_stream_collect_view", "orbfe_stream_in_flight",
+    "orbfe_stream_collect_view", "orbfe_stream_in_flight", "orbfe_track_frame",
 ]
 
 _lib = None
@@ -171,6 +182,7 @@ def lib():
     L.orbfe_match_bow.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, cf, ci, vp, vp]
     L.orbfe_match_bow_rig.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, cf, ci, vp, vp]
     L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
+    L.orbfe_track_frame.argtypes = [vp, vp, ci, C.POINTER(Frustum), C.POINTER(TrackParams), ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
@@ -406,6 +418,22 @@ class ExtractStream:
         nf, kp, desc, n, per = self.collect_raw()
         return [(kp[b, :n[b]].copy(), desc[b, :n[b]].copy(), per[b].copy()) for b in range(nf)]
 
+    def collect_view(self):
+        """orbfe_stream_collect_view: the oldest submission's results as numpy VIEWS of the slot's pinned block (no
+        copy); they stay valid until the submission that reuses the slot, `slots` submissions later.
+        Returns (n_frames, kp[slot_frames][cap], desc[slot_frames][cap][32], n[slot_frames], per[slot_frames][levels])."""
+        kp, desc, n, per = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nf = C.c_int()
+        self.ex._chk(self.L.orbfe_stream_collect_view(self.h, C.byref(kp), C.byref(desc), C.byref(n), C.byref(per), C.byref(nf)),
+                     "orbfe_stream_collect_view")
+        cap, nl, sf = self.ex.cap, self.ex.nlevels, self.slot_frames
+
+        def view(ptr, nbytes, dtype, shape):
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr.value), dtype=dtype).reshape(shape)
+
+        return (nf.value, view(kp, sf * cap * 24, KP_DTYPE, (sf, cap)), view(desc, sf * cap * 32, np.uint8, (sf, cap, 32)),
+                view(n, sf * 4, np.int32, (sf,)), view(per, sf * nl * 4, np.int32, (sf, nl)))
+
 
 class ORBmatcher:
     """ORB_SLAM3::ORBmatcher (include/ORBmatcher.h:36-84); statics bound to one extractor handle."""
@@ -594,6 +622,45 @@ class ORBmatcher:
                                                _p(fAngle), int(nLeft), nnRatio, int(checkOrientation), _p(out), C.byref(n)),
                     "orbfe_match_bow_rig")
         return n.value, out[:len(fDesc)].copy()
+
+
+class FrameTracker:
+    """The tracking thread's per-frame chain of this fork once the IMU is initialised -- Frame::Frame -> ExtractORB
+    (src/Tracking.cc:152-173, src/Frame.cc:178-189), the isInFrustum loop of Tracking::SearchLocalPoints (:1059-1077) and
+    ORBmatcher::SearchByProjection(mCurrentFrame, mvpLocalMapPoints, ...) (:1108-1115) -- as ONE call / one captured
+    hipGraph (orbfe_track_frame).  The grid statics are the frame's (src/Frame.cc:101-105)."""
+
+    def __init__(self, extractor, gridCols, gridRows, minX, minY, maxX, maxY):
+        self.e, self.L = extractor, extractor.L
+        self.grid = (int(gridCols), int(gridRows), float(minX), float(minY),
+                     float(np.float32(gridCols) / np.float32(np.float32(maxX) - np.float32(minX))),
+                     float(np.float32(gridRows) / np.float32(np.float32(maxY) - np.float32(minY))))
+
+    def TrackFrame(self, im, frustum, points, mpDesc, th, nnRatio, bFarPoints=False, thFarPoints=0.0):
+        """-> dict(kp, desc, per_level, mps, proj_xr, match, nmatches); kp is empty when the frame has no keypoints
+        (the reference returns early, src/Tracking.cc:158-159)."""
+        e = self.e
+        im = np.asarray(im)
+        assert im.dtype == np.uint8 and im.shape == (e.H, e.W) and im.strides[1] == 1
+        points = np.ascontiguousarray(points, WP_DTYPE)
+        mpDesc = np.ascontiguousarray(mpDesc, np.uint8)
+        M = len(points)
+        assert mpDesc.shape == (M, 32) or M == 0
+        tp = TrackParams()
+        (tp.grid_cols, tp.grid_rows, tp.min_x, tp.min_y, tp.grid_inv_w, tp.grid_inv_h) = self.grid
+        tp.th, tp.nn_ratio, tp.far_points, tp.th_far_points = th, nnRatio, int(bFarPoints), thFarPoints
+        kp = np.zeros(e.cap, KP_DTYPE)
+        desc = np.zeros((e.cap, 32), np.uint8)
+        per = np.zeros(e.nlevels, np.int32)
+        mps = np.zeros(max(M, 1), MP_DTYPE)
+        xr = np.zeros(max(M, 1), np.float32)
+        match = np.full(e.cap, -1, np.int32)
+        n, nm = C.c_int(), C.c_int()
+        e._chk(self.L.orbfe_track_frame(e.h, _p(im), im.strides[0], C.byref(frustum), C.byref(tp), M, _p(points), _p(mpDesc),
+                                        _p(kp), _p(desc), C.byref(n), _p(per), _p(mps), _p(xr), _p(match), C.byref(nm)),
+               "orbfe_track_frame")
+        k = n.value
+        return dict(kp=kp[:k], desc=desc[:k], per_level=per, mps=mps[:M], proj_xr=xr[:M], match=match[:k], nmatches=nm.value)
 
 
 class ImagePreparer:

@@ -1,6 +1,6 @@
 // Drives include/orbfe_adaptor.hpp the way src/Frame.cc:178-189 and src/Tracking.cc:1115 drive the
 // reference classes, with light mock Frame / MapPoint types that carry the members those functions read.
-//   usage: test_adaptor <W> <H> <gray.raw> <mps.bin> <M> <out.bin> [<voc.txt> <bow_out.txt>]
+//   usage: test_adaptor <W> <H> <gray.raw> <mps.bin> <M> <out.bin> [<voc.txt> <bow_out.txt> [<world.bin> <M2> <track_out.bin>]]
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -149,6 +149,55 @@ int main(int argc, char** argv)
             std::fprintf(fo, "\n");
         }
         fclose(fo);
+    }
+    if (argc >= 12) {  // the whole per-frame chain through FrameTracker (orbfe_track_frame): frame + local map -> matches
+        const auto wraw = slurp(argv[9]);  // M2 x (orbfe_world_point + 32 descriptor bytes + mnLastFrameSeen flag in .skip)
+        const int M2 = atoi(argv[10]);
+        const size_t wrec = sizeof(orbfe_world_point) + 32;
+        std::vector<std::shared_ptr<MapPoint>> local;
+        for (int i = 0; i < M2; i++) {
+            orbfe_world_point q;
+            std::memcpy(&q, wraw.data() + i * wrec, sizeof q);
+            auto p = std::make_shared<MapPoint>();
+            p->wp[0] = q.x; p->wp[1] = q.y; p->wp[2] = q.z;
+            p->mfMinDistance = q.min_distance; p->mfMaxDistance = q.max_distance;
+            p->bad = q.bad; p->obs = q.observations; p->mnLastFrameSeen = q.skip ? 7 : 0;
+            p->mbTrackInView = false;
+            std::memcpy(p->desc, wraw.data() + i * wrec + sizeof q, 32);
+            local.push_back(p);
+        }
+        orbfe_frustum fr{};
+        fr.rcw[0] = fr.rcw[4] = fr.rcw[8] = 1.0f;
+        fr.min_x = 0.f; fr.max_x = (float)W; fr.min_y = 0.f; fr.max_y = (float)H;
+        fr.fx = fr.fy = 400.f; fr.cx = 0.5f * (float)W; fr.cy = 0.5f * (float)H;
+        fr.mbf = 40.f; fr.log_scale_factor = 0.18232156f; fr.n_levels = 8; fr.camera_model = ORBFE_CAMERA_PINHOLE;
+        auto F2 = std::make_shared<Frame>();
+        F2->mvScaleFactors = ex.GetScaleFactors();
+        F2->mfGridElementWidthInv = (float)F2->cols / (float)(W - 0.f);
+        F2->mfGridElementHeightInv = (float)F2->rows / (float)(H - 0.f);
+        int nToMatch = 0;
+        const int nmT = FrameTracker::ExtractAndSearchLocalPoints(
+            ex, GrayImageView{img.data(), W}, F2, fr, 7, local, 40.f, false, 0.f, 0.75f,
+            [](const std::shared_ptr<MapPoint>& p) { return (const uint8_t*)p->desc; },
+            [](const std::shared_ptr<Frame>& f, const uint8_t* rows, int n) { f->mDescriptors.assign(rows, rows + (size_t)n * 32); },
+            &nToMatch);
+        std::ofstream ot(argv[11], std::ios::binary);
+        const int nT = F2->mNumKeypoints;
+        ot.write((const char*)&nT, 4);
+        ot.write((const char*)&nmT, 4);
+        ot.write((const char*)&nToMatch, 4);
+        ot.write((const char*)F2->mvKeysUn->data(), (std::streamsize)nT * sizeof(KeyPoint));
+        ot.write((const char*)F2->mDescriptors.data(), (std::streamsize)nT * 32);
+        for (int i = 0; i < nT; i++) {
+            int idx = -1;
+            for (int j = 0; j < M2 && F2->mvpMapPoints[i]; j++)
+                if (local[j] == F2->mvpMapPoints[i]) { idx = j; break; }
+            ot.write((const char*)&idx, 4);
+        }
+        for (auto& p : local) {
+            const int v = p->mbTrackInView ? p->mnTrackScaleLevel : -1;
+            ot.write((const char*)&v, 4);
+        }
     }
     {  // Tracking::SearchLocalPoints, src/Tracking.cc:1059-1077: project a deterministic cloud (identity pose)
         std::vector<std::shared_ptr<MapPoint>> cloud;

@@ -54,3 +54,30 @@ def world_points(n, dtype, names, seed=1):
     p[names["max_distance"]][:k] = (d[:k] * np.float32(1.2) ** np.arange(k)).astype(np.float32)
     p[names["min_distance"]][:k] = 0.0
     return p
+
+
+def world_points_on_keypoints(kp, desc, v, M, rng, n_levels, wp_dtype=None):
+    """map points that re-project onto keypoints of the frame (in the coordinates the matcher compares, S6): pose and
+    intrinsics of `v`, depths 1.5..9 m, distance range chosen so that PredictScale lands near the keypoint's octave"""
+    import match_scenarios as S
+    if wp_dtype is None:
+        import oracle_py
+        wp_dtype = oracle_py.WP_DTYPE
+    lo, hi = wp_dtype.names[3], wp_dtype.names[4]  # minDistance / maxDistance (oracle) or min_distance / max_distance (orbfe)
+    src = rng.integers(0, len(kp), M)
+    u = kp["x"][src] + rng.uniform(-2, 2, M)
+    w = kp["y"][src] + rng.uniform(-2, 2, M)
+    z = rng.uniform(1.5, 9.0, M)
+    pc = np.stack([(u - v["cx"]) / v["fx"] * z, (w - v["cy"]) / v["fy"] * z, z], 1)
+    R = np.asarray(v["rcw"], np.float64).reshape(3, 3)
+    pw = (R.T @ (pc - np.asarray(v["tcw"], np.float64)).T).T
+    pts = np.zeros(M, wp_dtype)
+    pts["x"], pts["y"], pts["z"] = pw[:, 0], pw[:, 1], pw[:, 2]
+    d = np.linalg.norm(pw - np.asarray(v["twc"], np.float64), axis=1)
+    pts[hi] = d * np.float32(1.2) ** kp["octave"][src].astype(np.float32) * rng.uniform(0.95, 1.05, M)
+    pts[lo] = pts[hi] / np.float32(1.2) ** (n_levels - 1)
+    pts["observations"] = rng.integers(0, 4, M)
+    pts["bad"] = rng.random(M) < 0.02
+    pts["skip"] = rng.random(M) < 0.02
+    mpd = np.stack([S.flip_bits(desc[s], int(rng.integers(0, 20)), rng) for s in src])
+    return pts, mpd

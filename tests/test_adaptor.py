@@ -72,8 +72,32 @@ def test_adaptor_matches_oracle(built, tmp_path):
     from test_vocab import ref_bow
     tree = vs.make_tree(10, 5, seed=9, early_leaf_p=0.03)
     vs.write_text(tree, str(tmp_path / "voc.txt"))
+    # FrameTracker::ExtractAndSearchLocalPoints (orbfe_track_frame): a local map that re-projects onto the frame's keypoints
+    import frustum_scenarios as FS
+    M2 = 1700
+    Ft = O.Frustum()
+    Ft.rcw[0] = Ft.rcw[4] = Ft.rcw[8] = 1.0
+    Ft.minX, Ft.maxX, Ft.minY, Ft.maxY = 0.0, float(W), 0.0, float(H)
+    Ft.fx = Ft.fy = 400.0
+    Ft.cx, Ft.cy, Ft.mbf, Ft.logScaleFactor, Ft.nLevels = 0.5 * W, 0.5 * H, 40.0, 0.18232156, 8
+    vt = dict(rcw=np.eye(3).reshape(-1), tcw=np.zeros(3), twc=np.zeros(3), fx=400.0, fy=400.0, cx=0.5 * W, cy=0.5 * H)
+    wpts, wdesc = FS.world_points_on_keypoints(kp_r, desc_r, vt, M2, np.random.default_rng(8), 8)
+    wrec = np.zeros(M2, np.dtype([("wp", O.WP_DTYPE), ("d", np.uint8, 32)]))
+    wrec["wp"], wrec["d"] = wpts, wdesc
+    (tmp_path / "w.bin").write_bytes(wrec.tobytes())
     stdout = subprocess.check_output([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "m.bin"), str(M),
-                                      str(tmp_path / "o.bin"), str(tmp_path / "voc.txt"), str(tmp_path / "bow.txt")]).decode()
+                                      str(tmp_path / "o.bin"), str(tmp_path / "voc.txt"), str(tmp_path / "bow.txt"),
+                                      str(tmp_path / "w.bin"), str(M2), str(tmp_path / "t.bin")]).decode()
+    mps_t, _ = O.is_in_frustum(Ft, wpts)
+    n_t, match_t = O.search_by_projection(fv, mps_t, wdesc, None, 40.0, 0.75)
+    rawt = (tmp_path / "t.bin").read_bytes()
+    nT, nmT, nToMatch = np.frombuffer(rawt[:12], np.int32)
+    assert nT == len(kp_r) and rawt[12:12 + 24 * nT] == kp_r.tobytes() and rawt[12 + 24 * nT:12 + 56 * nT] == desc_r.tobytes()
+    assert nmT == n_t and n_t > 500 and nToMatch == int(mps_t["inView"].sum())
+    assert np.array_equal(np.frombuffer(rawt[12 + 56 * nT:12 + 60 * nT], np.int32), match_t)
+    lvl = np.frombuffer(rawt[12 + 60 * nT:], np.int32)
+    untouched = (wpts["skip"] != 0) | (wpts["bad"] != 0)  # the reference does not visit them (src/Tracking.cc:1066-1069)
+    assert np.array_equal(lvl[~untouched], np.where(mps_t["inView"] == 1, mps_t["level"], -1)[~untouched]) and (lvl[untouched] == -1).all()
     # LocalPointProjector::ProjectLocalMapPoints on the driver's deterministic cloud == the oracle
     Fo = O.Frustum()
     Fo.rcw[0] = Fo.rcw[4] = Fo.rcw[8] = 1.0

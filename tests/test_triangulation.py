@@ -438,3 +438,29 @@ def test_gpu_kb8_triangulation_matches_oracle(built, seed, model2, has_cam2, ste
                                           check, cameras=cams)
         assert n == n_ref and np.array_equal(out, out_ref), (check, n, n_ref)
     assert n_ref > 10
+
+
+@pytest.mark.gpu
+def test_tri_params_of_another_layout_are_refused(built):
+    """orbfe_tri_params is versioned by its size (include/orbfe.h): a block whose struct_size is not this library's --
+    e.g. the shorter round-1 layout -- is refused with ORBFE_ERR_INVALID_ARG instead of being read past its end."""
+    import ctypes as C
+    import orbfe
+    e = orbfe.ORBextractor(500, 2000, 1.2, 8, 20, 7, 320, 240)
+    P = orbfe.TriParams()
+    assert P.struct_size == C.sizeof(orbfe.TriParams)
+    one = np.zeros(2, np.int32)
+    kp = np.zeros(1, orbfe.KP_DTYPE)
+    d = np.zeros((1, 32), np.uint8)
+    z = np.zeros(1, np.uint8)
+    sf = np.ones(8, np.float32)
+    out = np.zeros(1, np.int32)
+    n = C.c_int()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    call = lambda: e.L.orbfe_match_triangulation(e.h, 1, p(one), p(one), p(one), p(one), 1, p(kp), p(d), p(z), None, 1, p(kp), p(d),
+                                                 p(z), None, p(sf), 8, C.byref(P), p(out), C.byref(n))
+    assert call() == 0
+    for bad in (0, 56, C.sizeof(orbfe.TriParams) - 4, C.sizeof(orbfe.TriParams) + 4):
+        P.struct_size = bad
+        assert call() == 1  # ORBFE_ERR_INVALID_ARG
+        assert b"struct_size" in e.L.orbfe_last_error(e.h)
