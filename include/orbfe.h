@@ -420,6 +420,45 @@ int orbfe_match_triangulation(orbfe_handle *h, int n_groups, const int *kf1_off,
                               const uint8_t *stereo2, const float *scale_factors2, int n_levels2,
                               const orbfe_tri_params *params, int *matches12_out, int *n_matches);
 
+/* -------------------------------------------------------------------------------------------
+ * Key frames resident in HBM + the mapping thread's batched SearchForTriangulation
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orbfe_keyframe orbfe_keyframe;
+
+/* Uploads what the key-frame matchers read from a KeyFrame and what never changes after its construction
+ * (src/KeyFrame.cc:33-80): mvKeysUn (n keypoints), mDescriptors (n x 32), mFeatVec as node_id[i] = the
+ * DBoW2::FeatureVector key of feature i (the vocabulary node `levelsup` levels above its word, src/Frame.cc:483-495;
+ * -1 = the feature is in no node), stereo[i] != 0 iff mvuRight[i] >= 0 (NULL == monocular), mvScaleFactors.
+ * The features of a node are walked in ascending feature index, the order DBoW2 stores them in
+ * (Thirdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:1157-1170).  HOST pointers; one upload, then the key frame stays
+ * on the device until orbfe_keyframe_destroy.  Keypoint octaves must lie in [0, n_levels). */
+int orbfe_keyframe_create(orbfe_handle *h, int n, const orbfe_keypoint *kp, const uint8_t *desc, const int *node_id,
+                          const uint8_t *stereo, const float *scale_factors, int n_levels, orbfe_keyframe **out);
+void orbfe_keyframe_destroy(orbfe_keyframe *kf);
+int orbfe_keyframe_size(const orbfe_keyframe *kf);
+
+/* replaces the K calls ORBmatcher::SearchForTriangulation(mpCurrentKeyFrame, pKF2, vMatchedIndices, false, bCoarse, true)
+ * of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:455-488, up to 30 neighbours per new key frame) by ONE
+ * launch: kf1 against kf2[0..K), params[k] as orbfe_match_triangulation's for the pair (kf1, kf2[k]),
+ * has_mp1[i] / has_mp2[k][i] != 0 iff GetMapPoint(i) is set WHEN THE CALL IS MADE.
+ * Between two neighbours the reference turns matches into new map points (:500-700); a feature of key frame 1 that
+ * received one is skipped for the later neighbours (src/ORBmatcher.cc:506-509) and drops out of their rotation
+ * histograms.  So this call returns, per neighbour k and feature i1 of key frame 1, the RAW partner
+ * raw_match12[k * n1 + i1] (index in kf2[k] or -1) and its rotation bin raw_bin[k * n1 + i1] BEFORE the orientation
+ * filter; the caller walks the neighbours in order and calls orbfe_triangulation_select with the has_mp1 flags as they
+ * stand at that point.  That reproduces the K sequential calls exactly: vbMatched2 is never set in this fork
+ * (src/ORBmatcher.cc:485,537), so every feature of key frame 1 chooses its partner independently of the others, and the
+ * only state shared between neighbours is "idx1 already has a map point".  HOST pointers except the key frames. */
+int orbfe_match_triangulation_batch(orbfe_handle *h, const orbfe_keyframe *kf1, const uint8_t *has_mp1, int K,
+                                    const orbfe_keyframe *const *kf2, const uint8_t *const *has_mp2,
+                                    const orbfe_tri_params *params, int *raw_match12, uint8_t *raw_bin);
+/* host-only: vMatchedPairs / the return value of neighbour k's SearchForTriangulation call from the raw results of the
+ * batch call and the CURRENT flags of key frame 1: features with has_mp1_now[i1] != 0 drop out (:506-509), then the
+ * rotation histogram and ComputeThreeMaxima (:633-661, :1328-1370) when check_orientation.  raw_match12 / raw_bin point
+ * at neighbour k's n1 entries.  matches12_out[i1] = index in key frame 2 or -1. */
+int orbfe_triangulation_select(int n1, const int *raw_match12, const uint8_t *raw_bin, const uint8_t *has_mp1_now,
+                               int check_orientation, int *matches12_out, int *n_matches);
+
 /* replaces the search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false)
  * (src/ORBmatcher.cc:678-836; callers src/LocalMapping.cc:822,852): per map point the projection into the
  * key frame, KeyFrame::IsInImage, PredictScale, KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:790-833), the

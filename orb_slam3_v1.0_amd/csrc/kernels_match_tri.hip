@@ -10,8 +10,11 @@
 #include <algorithm>
 #include <cstring>
 
+#include <vector>
+
 #include "match_common.h"
 #include "device_math.h"
+#include "keyframe.h"
 
 #pragma clang fp contract(off)
 
@@ -293,6 +296,122 @@ __global__ __launch_bounds__(256) void tri_finalize_kernel(TriArgs A)
     if (tid == 0) *A.nMatches = sCount;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// One key frame against K neighbours in ONE launch (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:455-488: up to
+// 30 SearchForTriangulation calls per new key frame).  Key frames are RESIDENT in HBM (keyframe.h): keypoints,
+// descriptors and the FeatureVector as "features sorted by (vocabulary node, index)" + the list of distinct nodes, so a
+// call moves only what changes between calls -- the has-map-point flags and the per-pair geometry.  blockIdx.y = neighbour,
+// one thread per feature of key frame 1: binary search of its node in the neighbour's node list (staged in LDS), then the
+// sequential walk of that node's features exactly as tri_match_kernel does.
+// The rotation histogram is NOT applied here: between two neighbours the host turns matches into map points
+// (:500-700), and a feature of key frame 1 that received one is skipped for all later neighbours (:506-509) -- which also
+// changes their histograms.  The kernel therefore returns the RAW match and its rotation bin per (neighbour, feature),
+// computed from the has-map-point flags at the time of the call; orbfe_triangulation_select applies "skip the features
+// that got a map point meanwhile", the histogram and ComputeThreeMaxima for one neighbour at a time on the host.  Exact:
+// vbMatched2 is never set in this fork (:485,537), so every feature of key frame 1 chooses on its own and dropping one
+// never changes another's choice.
+// ---------------------------------------------------------------------------------------------
+struct TriNeighbour {  // device-side argument block of one (key frame 1, neighbour) pair
+    const orbfe_keypoint* kp2;
+    const uint8_t* desc2;
+    const uint8_t* stereo2;   // or null
+    const float* sf2;
+    const int* nodeList2;     // [G2] distinct vocabulary nodes of the neighbour, ascending
+    const int* nodeOff2;      // [G2 + 1]
+    const int* order2;        // features of the neighbour sorted by (node, index)
+    const uint8_t* hasMP2;    // [n2] flags of THIS call
+    int G2, n2;
+    float F12[9];
+    float epx, epy;
+    int onlyStereo, coarse, checkOrientation;
+    int model1, model2, kf1HasCamera2;
+    float cam1[8], cam2[8], kbPrecision;
+    float R12[9], t12[3];
+    float sigma2_1[kMaxLevels];
+};
+
+constexpr int kTriNodeLds = 4096;  // distinct nodes of a neighbour staged in LDS (more: the search reads global memory)
+
+__global__ __launch_bounds__(256) void tri_batch_kernel(const TriNeighbour* __restrict__ nbs, int n1,
+                                                        const orbfe_keypoint* __restrict__ kp1, const uint8_t* __restrict__ desc1,
+                                                        const int* __restrict__ node1, const uint8_t* __restrict__ stereo1,
+                                                        const uint8_t* __restrict__ hasMP1, int* __restrict__ rawMatch,
+                                                        uint8_t* __restrict__ rawBin)
+{
+    __shared__ int sNodes[kTriNodeLds];
+    const int k = blockIdx.y;
+    const TriNeighbour& A = nbs[k];
+    const int G2 = A.G2;
+    const bool nodesInLds = G2 <= kTriNodeLds;  // block-uniform
+    if (nodesInLds)
+        for (int g = threadIdx.x; g < G2; g += 256) sNodes[g] = A.nodeList2[g];
+    __syncthreads();
+    const int idx1 = blockIdx.x * 256 + threadIdx.x;
+    if (idx1 >= n1) return;
+    int bestDist = ORBFE_TH_LOW, bestIdx2 = -1, bin = 0;
+    const int nid = node1[idx1];
+    const bool bStereo1 = stereo1 && stereo1[idx1];
+    if (nid >= 0 && !hasMP1[idx1] && !(A.onlyStereo && !bStereo1)) {  // :506-509
+        int lo = 0, hi = G2;  // lower bound of nid in the neighbour's node list
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int v = nodesInLds ? sNodes[mid] : A.nodeList2[mid];
+            if (v < nid) lo = mid + 1;
+            else hi = mid;
+        }
+        const bool shared = lo < G2 && (nodesInLds ? sNodes[lo] : A.nodeList2[lo]) == nid;
+        if (shared) {
+            const orbfe_keypoint k1 = kp1[idx1];
+            unsigned long long d4[4];
+            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(desc1 + (size_t)idx1 * 32);
+            d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
+            const float a = (k1.x * A.F12[0] + k1.y * A.F12[3]) + A.F12[6];  // Pinhole.cpp:112-114
+            const float b = (k1.x * A.F12[1] + k1.y * A.F12[4]) + A.F12[7];
+            const float c = (k1.x * A.F12[2] + k1.y * A.F12[5]) + A.F12[8];
+            const float den = a * a + b * b;
+            for (int i2 = A.nodeOff2[lo]; i2 < A.nodeOff2[lo + 1]; i2++) {
+                const int idx2 = A.order2[i2];
+                if (A.hasMP2[idx2]) continue;  // :531
+                const bool bStereo2 = A.stereo2 && A.stereo2[idx2];
+                if (A.onlyStereo && !bStereo2) continue;
+                const int dist = hamming256(reinterpret_cast<const uint2*>(A.desc2 + (size_t)idx2 * 32), d4);
+                if (dist > ORBFE_TH_LOW || dist > bestDist) continue;  // :545
+                const orbfe_keypoint k2 = A.kp2[idx2];
+                if (!bStereo1 && !bStereo2 && !A.kf1HasCamera2) {  // :551-565
+                    const float distex = A.epx - k2.x, distey = A.epy - k2.y;
+                    const float err = distex * distex + distey * distey;
+                    if (err < 100 * A.sf2[k2.octave]) continue;
+                }
+                bool ok = false;
+                if (A.model1 == ORBFE_CAMERA_KANNALA_BRANDT8) {  // block-uniform
+                    if (!A.coarse)
+                        ok = kb8_epipolar(cam_of(A.cam1, A.model1), cam_of(A.cam2, A.model2), A.kbPrecision, k1.x, k1.y, k2.x, k2.y,
+                                          A.R12, A.t12, A.sigma2_1[k1.octave], 1.0f);
+                } else {
+                    const float num = (a * k2.x + b * k2.y) + c;
+                    if (den != 0) {
+                        const float dsqr = num * num / den;
+                        ok = (double)dsqr < 3.84 * 1.0;
+                    }
+                }
+                if (A.coarse || ok) {
+                    bestIdx2 = idx2;
+                    bestDist = dist;
+                }
+            }
+            if (bestIdx2 >= 0) {  // :619-627 (the bin is computed always; select uses it only with checkOrientation)
+                float rot = k1.angle - A.kp2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));
+                if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+            }
+        }
+    }
+    rawMatch[(size_t)k * n1 + idx1] = bestIdx2;
+    rawBin[(size_t)k * n1 + idx1] = (uint8_t)bin;
+}
+
 }  // namespace
 
 int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* off1, const int* idx1, const int* off2,
@@ -406,6 +525,151 @@ int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* of
     MCHK(hipStreamSynchronize(s));
     memcpy(matches12, hMatch, (size_t)n1 * sizeof(int));
     *nMatches = *hNM;
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resident key frames (keyframe.h)
+// ---------------------------------------------------------------------------------------------
+int keyframe_create(int n, const orbfe_keypoint* kp, const uint8_t* desc, const int* nodeId, const uint8_t* stereo,
+                    const float* sf, int nLevels, KeyFrameDev** out, std::string& err)
+{
+    *out = nullptr;
+    if (n < 0 || nLevels < 1 || nLevels > kMaxLevels || (n > 0 && (!kp || !desc || !nodeId)) || !sf) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < n; i++)
+        if (kp[i].octave < 0 || kp[i].octave >= nLevels) return ORBFE_ERR_INVALID_ARG;  // indexes mvScaleFactors / mvLevelSigma2
+    // FeatureVector as sorted arrays: features with a node, by (node, feature index) -- DBoW2 appends the features of a
+    // node in index order (TemplatedVocabulary.h:1157-1170), so this IS the order the reference walks them in
+    std::vector<int> order;
+    order.reserve((size_t)n);
+    for (int i = 0; i < n; i++)
+        if (nodeId[i] >= 0) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nodeId[a] < nodeId[b]; });
+    std::vector<int> nodeList, nodeOff;
+    for (size_t p = 0; p < order.size(); p++)
+        if (p == 0 || nodeId[order[p]] != nodeId[order[p - 1]]) {
+            nodeList.push_back(nodeId[order[p]]);
+            nodeOff.push_back((int)p);
+        }
+    nodeOff.push_back((int)order.size());
+    Carver c;
+    const size_t oKp = c.take((size_t)std::max(n, 1) * sizeof(orbfe_keypoint));
+    const size_t oDesc = c.take((size_t)std::max(n, 1) * 32);
+    const size_t oNode = c.take((size_t)std::max(n, 1) * sizeof(int));
+    const size_t oStereo = c.take((size_t)std::max(n, 1));
+    const size_t oSf = c.take((size_t)kMaxLevels * sizeof(float));
+    const size_t oOrder = c.take((order.size() + 1) * sizeof(int));
+    const size_t oList = c.take((nodeList.size() + 1) * sizeof(int));
+    const size_t oOff = c.take(nodeOff.size() * sizeof(int));
+    std::vector<uint8_t> img(c.off, 0);
+    if (n) {
+        memcpy(&img[oKp], kp, (size_t)n * sizeof(orbfe_keypoint));
+        memcpy(&img[oDesc], desc, (size_t)n * 32);
+        memcpy(&img[oNode], nodeId, (size_t)n * sizeof(int));
+        if (stereo) memcpy(&img[oStereo], stereo, (size_t)n);
+    }
+    memcpy(&img[oSf], sf, (size_t)nLevels * sizeof(float));
+    if (!order.empty()) memcpy(&img[oOrder], order.data(), order.size() * sizeof(int));
+    if (!nodeList.empty()) memcpy(&img[oList], nodeList.data(), nodeList.size() * sizeof(int));
+    memcpy(&img[oOff], nodeOff.data(), nodeOff.size() * sizeof(int));
+    KeyFrameDev* K = new (std::nothrow) KeyFrameDev();
+    if (!K) return ORBFE_ERR_OUT_OF_MEMORY;
+    if (hipMalloc(&K->block, c.off) != hipSuccess) {
+        (void)hipGetLastError();
+        delete K;
+        err = "hipMalloc(key frame) failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    if (hipMemcpy(K->block, img.data(), c.off, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(K->block);
+        delete K;
+        err = "upload of the key frame failed";
+        return ORBFE_ERR_HIP;
+    }
+    uint8_t* b = static_cast<uint8_t*>(K->block);
+    K->n = n;
+    K->nLevels = nLevels;
+    K->G = (int)nodeList.size();
+    K->hasStereo = stereo != nullptr;
+    K->kp = reinterpret_cast<const orbfe_keypoint*>(b + oKp);
+    K->desc = b + oDesc;
+    K->node = reinterpret_cast<const int*>(b + oNode);
+    K->stereo = stereo ? b + oStereo : nullptr;
+    K->sf = reinterpret_cast<const float*>(b + oSf);
+    K->order = reinterpret_cast<const int*>(b + oOrder);
+    K->nodeList = reinterpret_cast<const int*>(b + oList);
+    K->nodeOff = reinterpret_cast<const int*>(b + oOff);
+    K->bytes = c.off;
+    *out = K;
+    return ORBFE_OK;
+}
+
+void keyframe_destroy(KeyFrameDev* K)
+{
+    if (!K) return;
+    if (K->block) (void)hipFree(K->block);
+    delete K;
+}
+
+int match_triangulation_batch_run(MatchScratch& m, hipStream_t s, const KeyFrameDev* kf1, const uint8_t* hasMP1, int K,
+                                  const KeyFrameDev* const* kf2, const uint8_t* const* hasMP2, const orbfe_tri_params* P,
+                                  int* rawMatch, uint8_t* rawBin, std::string& err)
+{
+    const int n1 = kf1->n;
+    if (K == 0 || n1 == 0) return ORBFE_OK;
+    for (int k = 0; k < K; k++) {
+        if (!kf2[k] || (!hasMP2[k] && kf2[k]->n > 0)) return ORBFE_ERR_INVALID_ARG;
+        if (P[k].struct_size != (int)sizeof(orbfe_tri_params)) {
+            err = "orbfe_tri_params.struct_size does not match this library (rebuild the caller against include/orbfe.h)";
+            return ORBFE_ERR_INVALID_ARG;
+        }
+    }
+    // one pinned block up: [argument blocks | has_mp1 | has_mp2 of every neighbour]; one block down: [raw match | raw bin]
+    Carver in;
+    const size_t oArgs = in.take((size_t)K * sizeof(TriNeighbour));
+    const size_t oH1 = in.take((size_t)n1);
+    std::vector<size_t> oH2((size_t)K);
+    for (int k = 0; k < K; k++) oH2[(size_t)k] = in.take((size_t)std::max(kf2[k]->n, 1));
+    const size_t inBytes = in.off;
+    Carver sc = in;
+    const size_t oMatch = sc.take((size_t)K * n1 * sizeof(int));
+    const size_t oBin = sc.take((size_t)K * n1);
+    const size_t outBytes = sc.off - oMatch;
+    int rc = ensure(m, sc.off, inBytes + outBytes + 256, err);
+    if (rc != ORBFE_OK) return rc;
+    uint8_t* hp = static_cast<uint8_t*>(m.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(m.d);
+    TriNeighbour* args = reinterpret_cast<TriNeighbour*>(hp + oArgs);
+    memcpy(hp + oH1, hasMP1, (size_t)n1);
+    for (int k = 0; k < K; k++) {
+        const KeyFrameDev* F = kf2[k];
+        if (F->n) memcpy(hp + oH2[(size_t)k], hasMP2[k], (size_t)F->n);
+        TriNeighbour& A = args[k];
+        A.kp2 = F->kp; A.desc2 = F->desc; A.stereo2 = F->stereo; A.sf2 = F->sf;
+        A.nodeList2 = F->nodeList; A.nodeOff2 = F->nodeOff; A.order2 = F->order;
+        A.hasMP2 = dp + oH2[(size_t)k];
+        A.G2 = F->G; A.n2 = F->n;
+        const orbfe_tri_params& Q = P[k];
+        for (int i = 0; i < 9; i++) A.F12[i] = Q.f12[i];
+        A.epx = Q.ep_x; A.epy = Q.ep_y;
+        A.onlyStereo = Q.only_stereo; A.coarse = Q.coarse; A.checkOrientation = Q.check_orientation;
+        A.model1 = Q.camera_model1; A.model2 = Q.camera_model2; A.kf1HasCamera2 = Q.kf1_has_camera2;
+        for (int i = 0; i < 8; i++) { A.cam1[i] = Q.cam1[i]; A.cam2[i] = Q.cam2[i]; }
+        A.kbPrecision = Q.kb_precision;
+        for (int i = 0; i < 9; i++) A.R12[i] = Q.r12[i];
+        for (int i = 0; i < 3; i++) A.t12[i] = Q.t12[i];
+        for (int i = 0; i < kMaxLevels; i++) A.sigma2_1[i] = Q.level_sigma2_1[i];
+    }
+    MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(tri_batch_kernel, dim3((n1 + 255) / 256, K), dim3(256), 0, s, reinterpret_cast<const TriNeighbour*>(dp + oArgs), n1,
+                       kf1->kp, kf1->desc, kf1->node, kf1->stereo, dp + oH1, reinterpret_cast<int*>(dp + oMatch), dp + oBin);
+    MCHK(hipGetLastError());
+    uint8_t* hOut = hp + inBytes;
+    MCHK(hipMemcpyAsync(hOut, dp + oMatch, outBytes, hipMemcpyDeviceToHost, s));
+    MCHK(hipStreamSynchronize(s));
+    memcpy(rawMatch, hOut, (size_t)K * n1 * sizeof(int));
+    memcpy(rawBin, hOut + (oBin - oMatch), (size_t)K * n1);
     return ORBFE_OK;
 }
 

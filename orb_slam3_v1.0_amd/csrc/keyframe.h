@@ -1,0 +1,40 @@
+// keyframe.h -- key frames resident in HBM (kernels_match_tri.hip).
+//
+// What the key-frame matchers read from a KeyFrame and what never changes after its construction (src/KeyFrame.cc:33-80):
+// mvKeysUn, mDescriptors, mFeatVec, mvuRight >= 0, mvScaleFactors.  Uploaded once per key frame (56 B per feature + the
+// FeatureVector as sorted arrays: a 1000-feature key frame is 70 KB, ten thousand of them 0.7 GB of the 288 GB), so the
+// up to 30 SearchForTriangulation calls a new key frame triggers (src/LocalMapping.cc:455-488) move only the flags and the
+// per-pair geometry across PCIe.
+#pragma once
+#include <string>
+
+#include "match.h"
+
+namespace orbfe {
+
+struct KeyFrameDev {
+    void* block = nullptr;  // one allocation; the pointers below point into it
+    size_t bytes = 0;
+    int n = 0, nLevels = 0, G = 0;
+    bool hasStereo = false;
+    const orbfe_keypoint* kp = nullptr;
+    const uint8_t* desc = nullptr;
+    const int* node = nullptr;       // [n] vocabulary node of every feature (FeatureVector key), -1 = none
+    const uint8_t* stereo = nullptr; // [n] mvuRight >= 0, or null (monocular)
+    const float* sf = nullptr;       // mvScaleFactors
+    const int* order = nullptr;      // features with a node, sorted by (node, index)
+    const int* nodeList = nullptr;   // [G] distinct nodes, ascending
+    const int* nodeOff = nullptr;    // [G + 1] ranges of `order`
+};
+
+int keyframe_create(int n, const orbfe_keypoint* kp, const uint8_t* desc, const int* nodeId, const uint8_t* stereo,
+                    const float* sf, int nLevels, KeyFrameDev** out, std::string& err);
+void keyframe_destroy(KeyFrameDev* K);
+
+// SearchForTriangulation of key frame 1 against K neighbours in one launch: raw matches + rotation bins per (neighbour,
+// feature of key frame 1); the per-neighbour selection runs on the host (orbfe_triangulation_select)
+int match_triangulation_batch_run(MatchScratch& m, hipStream_t s, const KeyFrameDev* kf1, const uint8_t* hasMP1, int K,
+                                  const KeyFrameDev* const* kf2, const uint8_t* const* hasMP2, const orbfe_tri_params* P,
+                                  int* rawMatch, uint8_t* rawBin, std::string& err);
+
+}  // namespace orbfe

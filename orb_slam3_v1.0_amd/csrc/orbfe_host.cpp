@@ -22,6 +22,7 @@
 #include "match.h"
 #include "match_common.h"
 #include "match_proj.h"
+#include "keyframe.h"
 #include "prep.h"
 #include "vocab.h"
 
@@ -1646,6 +1647,101 @@ int orbfe_match_triangulation(orbfe_handle* h, int n_groups, const int* kf1_off,
                                            params, matches12_out, n_matches, err);
     if (rc != ORBFE_OK) h->err = err;
     return rc;
+}
+
+struct orbfe_keyframe {
+    orbfe::KeyFrameDev* k;
+    int device;
+};
+
+int orbfe_keyframe_create(orbfe_handle* h, int n, const orbfe_keypoint* kp, const uint8_t* desc, const int* node_id,
+                          const uint8_t* stereo, const float* scale_factors, int n_levels, orbfe_keyframe** out)
+{
+    if (!h || !out) return ORBFE_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    orbfe::KeyFrameDev* k = nullptr;
+    const int rc = keyframe_create(n, kp, desc, node_id, stereo, scale_factors, n_levels, &k, err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    *out = new orbfe_keyframe{k, h->device};
+    return ORBFE_OK;
+}
+
+void orbfe_keyframe_destroy(orbfe_keyframe* kf)
+{
+    if (!kf) return;
+    (void)hipSetDevice(kf->device);
+    keyframe_destroy(kf->k);
+    delete kf;
+}
+
+int orbfe_keyframe_size(const orbfe_keyframe* kf) { return kf ? kf->k->n : 0; }
+
+int orbfe_match_triangulation_batch(orbfe_handle* h, const orbfe_keyframe* kf1, const uint8_t* has_mp1, int K,
+                                    const orbfe_keyframe* const* kf2, const uint8_t* const* has_mp2,
+                                    const orbfe_tri_params* params, int* raw_match12, uint8_t* raw_bin)
+{
+    if (!h || !kf1 || K < 0 || K > 4096 || (K > 0 && (!kf2 || !has_mp2 || !params)) ||
+        (kf1->k->n > 0 && K > 0 && (!has_mp1 || !raw_match12 || !raw_bin)))
+        return ORBFE_ERR_INVALID_ARG;
+    std::vector<const orbfe::KeyFrameDev*> k2((size_t)K);
+    for (int k = 0; k < K; k++) {
+        if (!kf2[k] || kf2[k]->device != h->device) return ORBFE_ERR_INVALID_ARG;
+        k2[(size_t)k] = kf2[k]->k;
+    }
+    if (kf1->device != h->device) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
+    const int rc = match_triangulation_batch_run(h->match, h->stream, kf1->k, has_mp1, K, k2.data(), has_mp2, params, raw_match12,
+                                                 raw_bin, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+int orbfe_triangulation_select(int n1, const int* raw_match12, const uint8_t* raw_bin, const uint8_t* has_mp1_now,
+                               int check_orientation, int* matches12_out, int* n_matches)
+{
+    if (n1 < 0 || !n_matches || (n1 > 0 && (!raw_match12 || !raw_bin || !has_mp1_now || !matches12_out))) return ORBFE_ERR_INVALID_ARG;
+    int hist[ORBFE_HISTO_LENGTH] = {0};
+    int n = 0;
+    for (int i = 0; i < n1; i++) {
+        int m = has_mp1_now[i] ? -1 : raw_match12[i];  // src/ORBmatcher.cc:506-509
+        if (m >= 0) {
+            if (check_orientation && raw_bin[i] >= ORBFE_HISTO_LENGTH) return ORBFE_ERR_INVALID_ARG;
+            n++;
+            if (check_orientation) hist[raw_bin[i]]++;
+        }
+        matches12_out[i] = m;
+    }
+    if (check_orientation) {  // :633-661 with ComputeThreeMaxima :1328-1370
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < ORBFE_HISTO_LENGTH; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < n1; i++)
+            if (matches12_out[i] >= 0) {
+                const int b = raw_bin[i];
+                if (b != ind1 && b != ind2 && b != ind3) {
+                    matches12_out[i] = -1;
+                    n--;
+                }
+            }
+    }
+    *n_matches = n;
+    return ORBFE_OK;
 }
 
 int orbfe_distinctive_descriptors(orbfe_handle* h, int n_sets, const int* set_off, const uint8_t* desc, int* best_idx_out,

@@ -116,6 +116,8 @@ SYMBOLS = [
     "orbfe_project_map_points", "orbfe_project_map_points_device", "orbfe_fuse_search", "orbfe_fuse_search_right", "orbfe_fuse_search_sim3", "orbfe_search_by_sim3", "orbfe_match_projection_keyframe", "orbfe_match_triangulation", "orbfe_distinctive_descriptors", "orbfe_status_string", "orbfe_last_error", "orbfe_version",
     "orbfe_get_device_status", "orbfe_stream_create", "orbfe_stream_destroy", "orbfe_stream_submit", "orbfe_stream_collect",
     "orbfe_stream_collect_view", "orbfe_stream_in_flight", "orbfe_track_frame",
+    "orbfe_keyframe_create", "orbfe_keyframe_destroy", "orbfe_keyframe_size", "orbfe_match_triangulation_batch",
+    "orbfe_triangulation_select",
 ]
 
 _lib = None
@@ -200,6 +202,12 @@ def lib():
                                                   ci, vp, C.POINTER(ci)]
     L.orbfe_match_triangulation.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci,
                                             C.POINTER(TriParams), vp, vp]
+    L.orbfe_keyframe_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, C.POINTER(vp)]
+    L.orbfe_keyframe_destroy.argtypes = [vp]
+    L.orbfe_keyframe_destroy.restype = None
+    L.orbfe_keyframe_size.argtypes = [vp]
+    L.orbfe_match_triangulation_batch.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
+    L.orbfe_triangulation_select.argtypes = [ci, vp, vp, vp, ci, vp, vp]
     L.orbfe_distinctive_descriptors.argtypes = [vp, ci, vp, vp, vp, vp]
     L.orbfe_vocab_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, C.POINTER(vp)]
     L.orbfe_vocab_destroy.argtypes = [vp]
@@ -622,6 +630,73 @@ class ORBmatcher:
                                                _p(fAngle), int(nLeft), nnRatio, int(checkOrientation), _p(out), C.byref(n)),
                     "orbfe_match_bow_rig")
         return n.value, out[:len(fDesc)].copy()
+
+
+def tri_params(F12, ep, bOnlyStereo=False, bCoarse=False, checkOrientation=True, cameras=None):
+    """orbfe_tri_params of one key-frame pair (see ORBmatcher.SearchForTriangulation)"""
+    P = TriParams()
+    for i, v in enumerate(np.asarray(F12, np.float32).reshape(-1)):
+        P.f12[i] = float(v)
+    P.ep_x, P.ep_y = float(ep[0]), float(ep[1])
+    P.only_stereo, P.coarse, P.check_orientation = int(bOnlyStereo), int(bCoarse), int(checkOrientation)
+    if cameras is not None:
+        fill_tri_cameras(P, cameras)
+    return P
+
+
+class KeyFrame:
+    """A key frame resident in HBM (orbfe_keyframe_*): mvKeysUn, mDescriptors, mFeatVec (as the node of every feature, -1 =
+    none), mvuRight >= 0, mvScaleFactors -- what the key-frame matchers read and what never changes after construction."""
+
+    def __init__(self, extractor, kp, desc, nodeId, scaleFactors, stereo=None):
+        self.e, self.L = extractor, extractor.L
+        kp = np.ascontiguousarray(kp, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        node = np.ascontiguousarray(nodeId, np.int32)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        st = None if stereo is None else np.ascontiguousarray(stereo, np.uint8)
+        assert len(desc) == len(kp) == len(node)
+        self.n = len(kp)
+        self.h = C.c_void_p()
+        extractor._chk(self.L.orbfe_keyframe_create(extractor.h, self.n, _p(kp), _p(desc), _p(node), _p(st), _p(sf), len(sf),
+                                                    C.byref(self.h)), "orbfe_keyframe_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_keyframe_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def SearchForTriangulation_batch(extractor, kf1, hasMP1, kf2s, hasMP2s, params):
+    """orbfe_match_triangulation_batch: key frame kf1 against the neighbours kf2s in ONE launch -> (raw_match12 [K][n1],
+    raw_bin [K][n1]); walk the neighbours in order with triangulation_select and the flags as they stand then."""
+    K = len(kf2s)
+    h1 = np.ascontiguousarray(hasMP1, np.uint8)
+    h2 = [np.ascontiguousarray(v, np.uint8) for v in hasMP2s]
+    kfp = (C.c_void_p * max(K, 1))(*[k.h.value for k in kf2s])
+    h2p = (C.c_void_p * max(K, 1))(*[v.ctypes.data for v in h2])
+    P = (TriParams * max(K, 1))(*params)
+    raw = np.full((max(K, 1), max(kf1.n, 1)), -1, np.int32)
+    rbin = np.zeros((max(K, 1), max(kf1.n, 1)), np.uint8)
+    extractor._chk(extractor.L.orbfe_match_triangulation_batch(extractor.h, kf1.h, _p(h1), K, kfp, h2p, P, _p(raw), _p(rbin)),
+                   "orbfe_match_triangulation_batch")
+    return raw[:K, :kf1.n], rbin[:K, :kf1.n]
+
+
+def triangulation_select(raw_match12, raw_bin, hasMP1_now, checkOrientation=True):
+    """orbfe_triangulation_select (host-only): one neighbour's (nmatches, vMatches12) from its raw batch results and the
+    CURRENT has-map-point flags of key frame 1."""
+    raw = np.ascontiguousarray(raw_match12, np.int32)
+    rb = np.ascontiguousarray(raw_bin, np.uint8)
+    now = np.ascontiguousarray(hasMP1_now, np.uint8)
+    out = np.full(max(len(raw), 1), -1, np.int32)
+    n = C.c_int()
+    rc = lib().orbfe_triangulation_select(len(raw), _p(raw), _p(rb), _p(now), int(checkOrientation), _p(out), C.byref(n))
+    if rc != 0:
+        raise OrbfeError(rc, "orbfe_triangulation_select")
+    return n.value, out[:len(raw)]
 
 
 class FrameTracker:

@@ -113,6 +113,32 @@ def main():
                                          ex.mvScaleFactor, F12, ep, False, False, True),
         lambda: O.search_for_triangulation(off1, idx1, off2, idx2, kp, desc, h1, s1, kp2, d2, h2, s2, sf, F12, ep, False,
                                            False, True), eq2)
+    # the mapping thread's call shape (src/LocalMapping.cc:455-488): ONE key frame against K = 20 neighbours
+    import test_triangulation_batch as TB
+    K = 20
+    node1 = TB.nodes_of(kp)
+    nbs = [TB.neighbour(kp, desc, 500 + k, True, False) for k in range(K)]
+    csrs = [tuple(np.asarray(x, np.int32) for x in TB.csr(node1, nb["node"])) for nb in nbs]
+    kf1 = orbfe.KeyFrame(ex, kpp, desc, node1, ex.mvScaleFactor)
+    kf2 = [orbfe.KeyFrame(ex, nb["kp"].view(orbfe.KP_DTYPE), nb["desc"], nb["node"], ex.mvScaleFactor) for nb in nbs]
+    prm = [orbfe.tri_params(nb["F12"], nb["ep"], False, False, True) for nb in nbs]
+    has2 = [nb["has"] for nb in nbs]
+
+    def batch_gpu():
+        raw, rbin = orbfe.SearchForTriangulation_batch(ex, kf1, h1, kf2, has2, prm)
+        return [orbfe.triangulation_select(raw[k], rbin[k], h1, True) for k in range(K)]
+
+    def seq_gpu():
+        return [m.SearchForTriangulation(*csrs[k], kpp, desc, h1, None, nbs[k]["kp"].view(orbfe.KP_DTYPE), nbs[k]["desc"], has2[k],
+                                         None, ex.mvScaleFactor, nbs[k]["F12"], nbs[k]["ep"], False, False, True) for k in range(K)]
+
+    def seq_cpu():
+        return [O.search_for_triangulation(*csrs[k], kp, desc, h1, None, nbs[k]["kp"], nbs[k]["desc"], has2[k], None, sf,
+                                           nbs[k]["F12"], nbs[k]["ep"], False, False, True) for k in range(K)]
+
+    eqk = lambda g, c: all(a_[0] == b_[0] and np.array_equal(a_[1], b_[1]) for a_, b_ in zip(g, c))
+    row("orbfe_match_triangulation_batch K=20", "LocalMapping.cc:455-488", "N=%d, 20 resident neighbours" % n, batch_gpu, seq_cpu, eqk)
+    row("orbfe_match_triangulation x 20", "LocalMapping.cc:455-488", "N=%d, 20 single calls" % n, seq_gpu, seq_cpu, eqk)
     # SearchBySim3
     sc = T3.sim3_scenario(kp, desc, sf, 1)
     d12o, d21o, d12, d21 = O.Sim3Dir(), O.Sim3Dir(), orbfe.Sim3View(), orbfe.Sim3View()
