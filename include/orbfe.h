@@ -150,10 +150,11 @@ int orbfe_get_device_status(orbfe_handle *h, unsigned *flags_out);
  * (pageable sources have been copied by then, but the caller cannot rely on which path ran):
  * every source frame must stay valid and UNCHANGED until the submission that carried it has been
  * collected -- a capture buffer recycled earlier gives torn frames and no error.
- * Threading: an orbfe_stream and its handle are single-caller objects -- submit, collect, in_flight
- * and destroy must come from one thread at a time (the ring counters and the copy pool are not
- * synchronised between a submitting and a collecting thread); serialise them externally or keep the
- * producer / consumer split on the caller's side of one thread.
+ * Threading: ONE producer thread may submit while ONE consumer thread collects (the reference feeds frames from a grabber
+ * thread into the tracking thread, ros2_ws/src/mono-inertial/src/mono_inertial_node.cpp:207-210): the ring counters are
+ * atomic, a slot belongs to its submission until that has been collected, and the copy pool is serialised between the
+ * two.  Two threads submitting (or two collecting) at the same time, and destroy / orbfe_stream_enable_track while
+ * another call is running, are not supported.
  * ---------------------------------------------------------------------------------------- */
 typedef struct orbfe_stream orbfe_stream;
 int orbfe_stream_create(orbfe_handle *h, int slots, int slot_frames, orbfe_stream **out);
@@ -419,6 +420,39 @@ int orbfe_match_triangulation(orbfe_handle *h, int n_groups, const int *kf1_off,
                               const orbfe_keypoint *kp2, const uint8_t *desc2, const uint8_t *has_mp2,
                               const uint8_t *stereo2, const float *scale_factors2, int n_levels2,
                               const orbfe_tri_params *params, int *matches12_out, int *n_matches);
+
+/* -------------------------------------------------------------------------------------------
+ * Map points resident in HBM + the extract-and-match form of the ring
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orbfe_map orbfe_map;
+
+/* A device-resident table of what isInFrustum and SearchByProjection read from a MapPoint (GetWorldPos, mfMinDistance,
+ * mfMaxDistance, isBad, Observations: orbfe_world_point; GetDescriptor: 32 bytes), indexed by a caller-chosen id in
+ * [0, capacity).  The local map of consecutive frames is nearly the same set of points (src/Tracking.cc:1117-1230), so a
+ * frame names its points by id (4 bytes each) instead of shipping 64 bytes per point per frame across PCIe.
+ * orbfe_map_update (HOST pointers) writes entries ids[0..n) -- new points, and points whose position / descriptor /
+ * observation count changed; it is ordered behind everything submitted before it and returns when the table is updated.
+ * The `skip` member of the records is ignored (it is per frame: see orbfe_stream_submit_track). */
+int orbfe_map_create(orbfe_handle *h, int capacity, orbfe_map **out);
+void orbfe_map_destroy(orbfe_map *m);
+int orbfe_map_update(orbfe_handle *h, orbfe_map *m, int n, const int *ids, const orbfe_world_point *points,
+                     const uint8_t *desc);
+
+/* Gives the ring what it needs to run the whole per-frame chain of orbfe_track_frame per slot: extraction, isInFrustum
+ * of the frame's local map points against the frame's own pose, SearchByProjection -- H2D || extract + project + match ||
+ * D2H.  max_points = the largest n_points a submission will carry.  Call once, before the first submission. */
+int orbfe_stream_enable_track(orbfe_stream *s, orbfe_map *map, int max_points);
+/* orbfe_stream_submit + per frame b: frusta[b] (pose, bounds, camera of THAT frame) and the ids of its n_points local
+ * map points, ids[b * n_points + i]: id >= 0 = entry of the resident map; ~id (negative) = the same entry with
+ * "mnLastFrameSeen == current frame" (src/Tracking.cc:1066, skipped); an id outside the map = no point.  tp as
+ * orbfe_track_frame.  HOST pointers; everything is copied before the call returns except pinned frames (see above). */
+int orbfe_stream_submit_track(orbfe_stream *s, const uint8_t *const *grays, int pitch, int n, const orbfe_track_params *tp,
+                              const orbfe_frustum *frusta, int n_points, const int *ids);
+/* orbfe_stream_collect + the matches of a submission made with orbfe_stream_submit_track: match_out[b * cap + i] =
+ * position in frame b's id list of the map point written to mvpMapPoints[i], or -1 (cap = orbfe_max_keypoints());
+ * n_matches[b] = the return value of SearchByProjection.  Byte-identical to orbfe_track_frame per frame. */
+int orbfe_stream_collect_track(orbfe_stream *s, orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out, int *per_level_counts,
+                               int *match_out, int *n_matches, int *n_frames);
 
 /* -------------------------------------------------------------------------------------------
  * Key frames resident in HBM + the mapping thread's batched SearchForTriangulation

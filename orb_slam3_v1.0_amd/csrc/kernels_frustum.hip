@@ -91,6 +91,54 @@ __global__ __launch_bounds__(256) void frustum_dev_kernel(const orbfe_frustum* _
     frustum_point(F, i, pts, out, projXR);
 }
 
+// Streaming / resident-map form (orbfe_map, orbfe_stream_submit_track): frame b = blockIdx.y reads ITS frustum and ITS list
+// of map-point ids; id >= 0 names an entry of the resident map, ~id (negative) the same entry with "mnLastFrameSeen ==
+// current frame" (src/Tracking.cc:1066: skipped), ids outside the map give a bad record.  Besides the record
+// SearchByProjection reads, the descriptor is copied next to it so that the matcher finds frame b's descriptors contiguous.
+__global__ __launch_bounds__(256) void frustum_gather_kernel(const orbfe_frustum* __restrict__ dF, const int* __restrict__ ids, int M,
+                                                             int mapCap, const orbfe_world_point* __restrict__ mapPts,
+                                                             const uint8_t* __restrict__ mapDesc, orbfe_map_point* __restrict__ out,
+                                                             uint8_t* __restrict__ descOut)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int b = blockIdx.y;
+    const orbfe_frustum F = dF[b];  // block-uniform: scalar loads
+    const int raw = ids[(size_t)b * M + i];
+    const int id = raw < 0 ? ~raw : raw;
+    orbfe_world_point p{};
+    uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+    if (id < mapCap) {
+        p = mapPts[id];
+        const uint4* dp = reinterpret_cast<const uint4*>(mapDesc + (size_t)id * 32);
+        d0 = dp[0];
+        d1 = dp[1];
+        p.skip = raw < 0 ? 1 : 0;
+    } else {
+        p.bad = 1;
+        p.skip = 1;
+    }
+    frustum_point(F, 0, &p, out + (size_t)b * M + i, nullptr);
+    uint4* dd = reinterpret_cast<uint4*>(descOut + ((size_t)b * M + i) * 32);
+    dd[0] = d0;
+    dd[1] = d1;
+}
+
+__global__ __launch_bounds__(256) void map_scatter_kernel(int n, const int* __restrict__ ids, const orbfe_world_point* __restrict__ pts,
+                                                          const uint8_t* __restrict__ desc, int mapCap,
+                                                          orbfe_world_point* __restrict__ mapPts, uint8_t* __restrict__ mapDesc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int id = ids[i];
+    if (id < 0 || id >= mapCap) return;  // validated on the host; never written
+    mapPts[id] = pts[i];
+    const uint4* sp = reinterpret_cast<const uint4*>(desc + (size_t)i * 32);
+    uint4* dp = reinterpret_cast<uint4*>(mapDesc + (size_t)id * 32);
+    dp[0] = sp[0];
+    dp[1] = sp[1];
+}
+
 }  // namespace
 
 int frustum_validate(const orbfe_frustum* F)
@@ -122,6 +170,33 @@ int frustum_launch_dev(hipStream_t s, const orbfe_frustum* dF, int n, const orbf
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         err = std::string("frustum_dev_kernel: ") + hipGetErrorString(e);
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+int frustum_gather_launch(hipStream_t s, int B, const orbfe_frustum* dF, const int* dIds, int M, int mapCap,
+                          const orbfe_world_point* mapPts, const uint8_t* mapDesc, orbfe_map_point* dOut, uint8_t* dDescOut,
+                          std::string& err)
+{
+    if (B == 0 || M == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(frustum_gather_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, dF, dIds, M, mapCap, mapPts, mapDesc, dOut, dDescOut);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        err = std::string("frustum_gather_kernel: ") + hipGetErrorString(e);
+        return ORBFE_ERR_HIP;
+    }
+    return ORBFE_OK;
+}
+
+int map_scatter_launch(hipStream_t s, int n, const int* dIds, const orbfe_world_point* dPts, const uint8_t* dDesc, int mapCap,
+                       orbfe_world_point* mapPts, uint8_t* mapDesc, std::string& err)
+{
+    if (n == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(map_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, dIds, dPts, dDesc, mapCap, mapPts, mapDesc);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        err = std::string("map_scatter_kernel: ") + hipGetErrorString(e);
         return ORBFE_ERR_HIP;
     }
     return ORBFE_OK;

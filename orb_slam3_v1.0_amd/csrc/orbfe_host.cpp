@@ -5,6 +5,7 @@
 // (:433-541) and extractFeatures (:543-585) -- but as ONE ordered chain of asynchronous kernel
 // launches on one HIP stream, with no host synchronisation between stages (the reference syncs
 // >= 8 times per level) and no per-frame allocation.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1074,11 +1075,25 @@ struct StreamSlot {
     uint8_t* dIn = nullptr;
     uint8_t* dOut = nullptr;  // [n | status | per-level | keypoints | descriptors], the handle's block layout
     uint8_t* hOut = nullptr;  // pinned mirror
+    // extract-and-match submissions (orbfe_stream_enable_track): per frame frustum + map-point ids up, matches down
+    uint8_t* hTrkIn = nullptr;   // pinned [frusta (slotFrames) | ids (slotFrames x maxPoints)]
+    uint8_t* dTrkIn = nullptr;
+    uint8_t* dTrkWork = nullptr; // [map-point records | gathered descriptors]
+    uint8_t* dTrkOut = nullptr;  // [n_matches (slotFrames) | match (slotFrames x cap)]
+    uint8_t* hTrkOut = nullptr;  // pinned mirror
     hipEvent_t evIn = nullptr, evDone = nullptr, evOut = nullptr;
     int n = 0;
+    bool track = false;
 };
 
 }  // namespace
+
+struct orbfe_map {
+    orbfe_handle* h = nullptr;
+    int cap = 0;
+    orbfe_world_point* dPts = nullptr;
+    uint8_t* dDesc = nullptr;
+};
 
 struct orbfe_stream {
     orbfe_handle* h = nullptr;
@@ -1086,8 +1101,15 @@ struct orbfe_stream {
     size_t inFrame = 0, outBytes = 0, offStatus = 0, offPer = 0, offKp = 0, offDesc = 0;
     hipStream_t sIn = nullptr, sOut = nullptr;  // upload / download; the kernels run on the handle's stream
     std::vector<StreamSlot> slots;
-    unsigned long long submitted = 0, collected = 0;
+    // one producer (submit) and one consumer (collect) may run concurrently: a slot belongs to its submission from the
+    // moment `submitted` passes it until `collected` does
+    std::atomic<unsigned long long> submitted{0}, collected{0};
     RowCopyPool* pool = nullptr;
+    std::mutex poolMu;  // RowCopyPool::parallel_for is not re-entrant: the two sides take turns
+    // extract-and-match
+    orbfe_map* map = nullptr;
+    int maxPoints = 0;
+    size_t trkInBytes = 0, offIds = 0, trkWorkBytes = 0, offGatherDesc = 0, trkOutBytes = 0, offMatch = 0;
 };
 
 extern "C" {
@@ -1105,6 +1127,11 @@ void orbfe_stream_destroy(orbfe_stream* st)
         if (sl.dIn) (void)hipFree(sl.dIn);
         if (sl.dOut) (void)hipFree(sl.dOut);
         if (sl.hOut) (void)hipHostFree(sl.hOut);
+        if (sl.hTrkIn) (void)hipHostFree(sl.hTrkIn);
+        if (sl.dTrkIn) (void)hipFree(sl.dTrkIn);
+        if (sl.dTrkWork) (void)hipFree(sl.dTrkWork);
+        if (sl.dTrkOut) (void)hipFree(sl.dTrkOut);
+        if (sl.hTrkOut) (void)hipHostFree(sl.hTrkOut);
         for (hipEvent_t e : {sl.evIn, sl.evDone, sl.evOut})
             if (e) (void)hipEventDestroy(e);
     }
@@ -1159,17 +1186,31 @@ int orbfe_stream_create(orbfe_handle* h, int slots, int slot_frames, orbfe_strea
     return ORBFE_OK;
 }
 
-int orbfe_stream_in_flight(const orbfe_stream* st) { return st ? (int)(st->submitted - st->collected) : 0; }
+int orbfe_stream_in_flight(const orbfe_stream* st)
+{
+    return st ? (int)(st->submitted.load(std::memory_order_acquire) - st->collected.load(std::memory_order_acquire)) : 0;
+}
 
-int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch, int n)
+// the common submission: upload, extraction chain, optionally projection + SearchByProjection of the slot's frames, download
+static int stream_submit_impl(orbfe_stream* st, const uint8_t* const* grays, int pitch, int n, const orbfe_track_params* tp,
+                              const orbfe_frustum* frusta, int nPoints, const int* ids)
 {
     if (!st || !grays || n < 1 || n > st->slotFrames) return ORBFE_ERR_INVALID_ARG;
     orbfe_handle* h = st->h;
     if (pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
-    if (st->submitted - st->collected >= (unsigned long long)st->nSlots) return ORBFE_ERR_BUSY;
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(h, hipSetDevice(h->device));
-    StreamSlot& sl = st->slots[st->submitted % st->nSlots];
+    const bool track = tp != nullptr;
+    if (track) {
+        if (!st->map || !frusta || nPoints < 0 || nPoints > st->maxPoints || (nPoints > 0 && !ids)) return ORBFE_ERR_INVALID_ARG;
+        if (tp->struct_size != (int)sizeof(orbfe_track_params) || tp->grid_cols < 1 || tp->grid_rows < 1) return ORBFE_ERR_INVALID_ARG;
+        for (int b = 0; b < n; b++) {
+            const int rcf = frustum_validate(&frusta[b]);
+            if (rcf != ORBFE_OK) return rcf;
+            if (frusta[b].n_levels > h->nLevels) return ORBFE_ERR_INVALID_ARG;
+        }
+    }
+    const unsigned long long seq = st->submitted.load(std::memory_order_relaxed);
+    if (seq - st->collected.load(std::memory_order_acquire) >= (unsigned long long)st->nSlots) return ORBFE_ERR_BUSY;
+    StreamSlot& sl = st->slots[seq % st->nSlots];
     const int W = h->prm.image_width, H = h->prm.image_height;
     // (the slot was collected: its previous upload, kernels and download have completed -- evOut was waited for)
     bool direct = pitch <= h->dInPitch && (pitch & 3) == 0;
@@ -1186,6 +1227,34 @@ int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch
     }
     int stagedPitch = h->dInPitch;
     size_t frameStride = st->inFrame;
+    if (!direct) {
+        // pageable sources go through the slot's pinned staging block on a pool of copy threads -- BEFORE the handle is
+        // locked: a consumer thread's collect may need the handle meanwhile.  A dword-aligned source pitch is kept (the
+        // kernels read it as it is), so a band of rows is ONE contiguous copy; other pitches are re-pitched row by row.
+        const bool keep = (pitch & 3) == 0 && pitch <= h->dInPitch;
+        const int dp = keep ? pitch : h->dInPitch;
+        const size_t inFrame = st->inFrame;
+        uint8_t* hIn = sl.hIn;
+        const int bands = 4;  // row bands per frame so that a handful of frames still spreads over the pool
+        std::lock_guard<std::mutex> pk(st->poolMu);
+        st->pool->parallel_for(n * bands, [&](int job) {
+            const int b = job / bands, band = job - b * bands;
+            const int y0 = H * band / bands, y1 = H * (band + 1) / bands;
+            if (keep) {
+                const size_t bytes = (size_t)(y1 - y0 - 1) * pitch + (size_t)W;
+                memcpy(hIn + b * inFrame + (size_t)y0 * dp, grays[b] + (size_t)y0 * pitch, bytes);
+            } else {
+                for (int y = y0; y < y1; y++) memcpy(hIn + b * inFrame + (size_t)y * dp, grays[b] + (size_t)y * pitch, (size_t)W);
+            }
+        });
+        stagedPitch = dp;
+    }
+    if (track) {  // [frusta | ids] of the slot into its pinned block
+        memcpy(sl.hTrkIn, frusta, (size_t)n * sizeof(orbfe_frustum));
+        if (nPoints) memcpy(sl.hTrkIn + st->offIds, ids, (size_t)n * nPoints * sizeof(int));
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
     if (direct) {
         // pinned sources: DMA straight from the caller's memory.  Frames that sit at a constant distance (a packed
         // [n][H][pitch] block is the usual case) go as ONE copy and keep that distance on the device.
@@ -1202,35 +1271,44 @@ int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch
                 HIPCHK(h, hipMemcpyAsync(sl.dIn + b * st->inFrame, grays[b], std::min(bytes, st->inFrame), hipMemcpyHostToDevice, st->sIn));
         }
     } else {
-        // pageable sources go through the slot's pinned staging block on a pool of copy threads.  A dword-aligned source
-        // pitch is kept (the kernels read it as it is), so a band of rows is ONE contiguous copy; other pitches are
-        // re-pitched row by row.
-        const bool keep = (pitch & 3) == 0 && pitch <= h->dInPitch;
-        const int dp = keep ? pitch : h->dInPitch;
-        const size_t inFrame = st->inFrame;
-        uint8_t* hIn = sl.hIn;
-        const int bands = 4;  // row bands per frame so that a handful of frames still spreads over the pool
-        st->pool->parallel_for(n * bands, [&](int job) {
-            const int b = job / bands, band = job - b * bands;
-            const int y0 = H * band / bands, y1 = H * (band + 1) / bands;
-            if (keep) {
-                const size_t bytes = (size_t)(y1 - y0 - 1) * pitch + (size_t)W;
-                memcpy(hIn + b * inFrame + (size_t)y0 * dp, grays[b] + (size_t)y0 * pitch, bytes);
-            } else {
-                for (int y = y0; y < y1; y++) memcpy(hIn + b * inFrame + (size_t)y * dp, grays[b] + (size_t)y * pitch, (size_t)W);
-            }
-        });
-        stagedPitch = dp;
         HIPCHK(h, hipMemcpyAsync(sl.dIn, sl.hIn, st->inFrame * (size_t)n, hipMemcpyHostToDevice, st->sIn));
+    }
+    if (track) {
+        HIPCHK(h, hipMemcpyAsync(sl.dTrkIn, sl.hTrkIn, (size_t)n * sizeof(orbfe_frustum), hipMemcpyHostToDevice, st->sIn));
+        if (nPoints)
+            HIPCHK(h, hipMemcpyAsync(sl.dTrkIn + st->offIds, sl.hTrkIn + st->offIds, (size_t)n * nPoints * sizeof(int), hipMemcpyHostToDevice,
+                                     st->sIn));
     }
     HIPCHK(h, hipEventRecord(sl.evIn, st->sIn));
     // kernels on the handle's stream, behind the upload
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.evIn, 0));
     const int inPitch = direct ? pitch : stagedPitch;
-    const int rc = extract_chain(h, sl.dIn, frameStride, inPitch, n, reinterpret_cast<orbfe_keypoint*>(sl.dOut + st->offKp),
-                                 sl.dOut + st->offDesc, reinterpret_cast<int*>(sl.dOut), reinterpret_cast<int*>(sl.dOut + st->offPer),
-                                 reinterpret_cast<int*>(sl.dOut + st->offStatus), h->stream);
+    orbfe_keypoint* dKp = reinterpret_cast<orbfe_keypoint*>(sl.dOut + st->offKp);
+    const int rc = extract_chain(h, sl.dIn, frameStride, inPitch, n, dKp, sl.dOut + st->offDesc, reinterpret_cast<int*>(sl.dOut),
+                                 reinterpret_cast<int*>(sl.dOut + st->offPer), reinterpret_cast<int*>(sl.dOut + st->offStatus), h->stream);
     if (rc != ORBFE_OK) return rc;
+    if (track) {
+        std::string err;
+        orbfe_map_point* dMps = reinterpret_cast<orbfe_map_point*>(sl.dTrkWork);
+        uint8_t* dMpDesc = sl.dTrkWork + st->offGatherDesc;
+        int rcm = frustum_gather_launch(h->stream, n, reinterpret_cast<const orbfe_frustum*>(sl.dTrkIn),
+                                        reinterpret_cast<const int*>(sl.dTrkIn + st->offIds), nPoints, st->map->cap, st->map->dPts,
+                                        st->map->dDesc, dMps, dMpDesc, err);
+        if (rcm == ORBFE_OK) {
+            MatchScope scope_(h, h->stream);
+            rcm = scope_.rc;
+            if (rcm == ORBFE_OK)
+                rcm = match_projection_batch_device(h->match, h->stream, n, dKp, sl.dOut + st->offDesc, reinterpret_cast<const int*>(sl.dOut),
+                                                    h->P.kpCapFrame, tp->grid_cols, tp->grid_rows, tp->min_x, tp->min_y, tp->grid_inv_w,
+                                                    tp->grid_inv_h, h->dSf, h->nLevels, nPoints, dMps, dMpDesc, nullptr, tp->th, tp->far_points,
+                                                    tp->th_far_points, tp->nn_ratio, reinterpret_cast<int*>(sl.dTrkOut + st->offMatch),
+                                                    reinterpret_cast<int*>(sl.dTrkOut), err);
+        }
+        if (rcm != ORBFE_OK) {
+            h->err = err;
+            return rcm;
+        }
+    }
     HIPCHK(h, hipEventRecord(sl.evDone, h->stream));
     // download behind the kernels: the whole block for a full slot (one copy), the used parts otherwise
     HIPCHK(h, hipStreamWaitEvent(st->sOut, sl.evDone, 0));
@@ -1244,20 +1322,81 @@ int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch
         HIPCHK(h, hipMemcpyAsync(sl.hOut + st->offKp, sl.dOut + st->offKp, (size_t)n * cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, st->sOut));
         HIPCHK(h, hipMemcpyAsync(sl.hOut + st->offDesc, sl.dOut + st->offDesc, (size_t)n * cap * ORBFE_DESC_BYTES, hipMemcpyDeviceToHost, st->sOut));
     }
+    if (track) {
+        const size_t cap = (size_t)h->P.kpCapFrame;
+        if (n == st->slotFrames) {
+            HIPCHK(h, hipMemcpyAsync(sl.hTrkOut, sl.dTrkOut, st->trkOutBytes, hipMemcpyDeviceToHost, st->sOut));
+        } else {
+            HIPCHK(h, hipMemcpyAsync(sl.hTrkOut, sl.dTrkOut, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st->sOut));
+            HIPCHK(h, hipMemcpyAsync(sl.hTrkOut + st->offMatch, sl.dTrkOut + st->offMatch, (size_t)n * cap * sizeof(int), hipMemcpyDeviceToHost,
+                                     st->sOut));
+        }
+    }
     HIPCHK(h, hipEventRecord(sl.evOut, st->sOut));
     sl.n = n;
-    st->submitted++;
+    sl.track = track;
+    st->submitted.store(seq + 1, std::memory_order_release);
+    return ORBFE_OK;
+}
+
+int orbfe_stream_submit(orbfe_stream* st, const uint8_t* const* grays, int pitch, int n)
+{
+    return stream_submit_impl(st, grays, pitch, n, nullptr, nullptr, 0, nullptr);
+}
+
+int orbfe_stream_submit_track(orbfe_stream* st, const uint8_t* const* grays, int pitch, int n, const orbfe_track_params* tp,
+                              const orbfe_frustum* frusta, int n_points, const int* ids)
+{
+    if (!tp) return ORBFE_ERR_INVALID_ARG;
+    return stream_submit_impl(st, grays, pitch, n, tp, frusta, n_points, ids);
+}
+
+int orbfe_stream_enable_track(orbfe_stream* st, orbfe_map* map, int max_points)
+{
+    if (!st || !map || map->h != st->h || max_points < 1 || max_points > (1 << 24)) return ORBFE_ERR_INVALID_ARG;
+    if (st->map || st->submitted.load() != st->collected.load()) return ORBFE_ERR_INVALID_ARG;  // once, on an idle ring
+    orbfe_handle* h = st->h;
+    if (h->P.kpCapFrame >= (1 << 20)) return ORBFE_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t F = (size_t)st->slotFrames, M = (size_t)max_points, cap = (size_t)h->P.kpCapFrame;
+    st->offIds = align_up(F * sizeof(orbfe_frustum), 256);
+    st->trkInBytes = st->offIds + F * M * sizeof(int);
+    st->offGatherDesc = align_up(F * M * sizeof(orbfe_map_point), 256);
+    st->trkWorkBytes = st->offGatherDesc + F * M * ORBFE_DESC_BYTES;
+    st->offMatch = align_up(F * sizeof(int), 256);
+    st->trkOutBytes = st->offMatch + F * cap * sizeof(int);
+    bool ok = true;
+    for (auto& sl : st->slots)
+        ok = ok && hipHostMalloc(&sl.hTrkIn, st->trkInBytes) == hipSuccess && hipMalloc(&sl.dTrkIn, st->trkInBytes) == hipSuccess &&
+             hipMalloc(&sl.dTrkWork, st->trkWorkBytes) == hipSuccess && hipMalloc(&sl.dTrkOut, st->trkOutBytes) == hipSuccess &&
+             hipHostMalloc(&sl.hTrkOut, st->trkOutBytes) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        h->err = "orbfe_stream_enable_track: allocation failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;  // (what was allocated is released by orbfe_stream_destroy)
+    }
+    st->map = map;
+    st->maxPoints = max_points;
     return ORBFE_OK;
 }
 
 // waits for the oldest submission and checks its guard flags; *slot_out stays in flight until the caller bumps `collected`
 static int stream_wait_oldest(orbfe_stream* st, StreamSlot** slot_out)
 {
-    if (!st || st->submitted == st->collected) return ORBFE_ERR_INVALID_ARG;
+    if (!st) return ORBFE_ERR_INVALID_ARG;
+    const unsigned long long seq = st->collected.load(std::memory_order_relaxed);
+    if (st->submitted.load(std::memory_order_acquire) == seq) return ORBFE_ERR_INVALID_ARG;
     orbfe_handle* h = st->h;
-    StreamSlot& sl = st->slots[st->collected % st->nSlots];
+    StreamSlot& sl = st->slots[seq % st->nSlots];
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipEventSynchronize(sl.evOut));
+    {
+        const hipError_t e = hipEventSynchronize(sl.evOut);  // (no handle lock: a producer may be submitting right now)
+        if (e != hipSuccess) {
+            std::lock_guard<std::mutex> lk(h->mu);
+            return fail_hip(h, e, "hipEventSynchronize(slot)", __LINE__);
+        }
+    }
     *slot_out = &sl;
     const int* status = reinterpret_cast<const int*>(sl.hOut + st->offStatus);
     for (int b = 0; b < sl.n; b++)
@@ -1266,7 +1405,7 @@ static int stream_wait_oldest(orbfe_stream* st, StreamSlot** slot_out)
             snprintf(buf, sizeof buf, "device guard flags 0x%x at frame %d of the collected submission", (unsigned)status[b], b);
             std::lock_guard<std::mutex> lk(h->mu);
             h->err = buf;
-            st->collected++;
+            st->collected.store(seq + 1, std::memory_order_release);
             return ORBFE_ERR_INTERNAL;
         }
     return ORBFE_OK;
@@ -1283,33 +1422,145 @@ int orbfe_stream_collect_view(orbfe_stream* st, const orbfe_keypoint** kp, const
     if (n) *n = reinterpret_cast<const int*>(sl->hOut);
     if (per_level) *per_level = reinterpret_cast<const int*>(sl->hOut + st->offPer);
     if (n_frames) *n_frames = sl->n;
-    st->collected++;
+    st->collected.fetch_add(1, std::memory_order_release);
     return ORBFE_OK;
 }
 
-int orbfe_stream_collect(orbfe_stream* st, orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, int* n_frames)
+static int stream_collect_impl(orbfe_stream* st, orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, int* match_out,
+                               int* n_matches, int* n_frames, bool wantTrack)
 {
-    if (!st || !kp_out || !desc_out || !n_out) return ORBFE_ERR_INVALID_ARG;
+    if (!st || !kp_out || !desc_out || !n_out || (wantTrack && (!match_out || !n_matches))) return ORBFE_ERR_INVALID_ARG;
     StreamSlot* sl = nullptr;
     const int rc = stream_wait_oldest(st, &sl);
     if (rc != ORBFE_OK) return rc;
     orbfe_handle* h = st->h;
+    if (wantTrack && !sl->track) {  // the oldest submission carried no map points: leave it in flight for orbfe_stream_collect
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->err = "orbfe_stream_collect_track: the oldest submission was made with orbfe_stream_submit";
+        return ORBFE_ERR_INVALID_ARG;
+    }
     const size_t cap = (size_t)h->P.kpCapFrame;
     const int nL = h->nLevels;
     const int* hn = reinterpret_cast<const int*>(sl->hOut);
     const orbfe_keypoint* hkp = reinterpret_cast<const orbfe_keypoint*>(sl->hOut + st->offKp);
     const uint8_t* hdesc = sl->hOut + st->offDesc;
     const int* hper = reinterpret_cast<const int*>(sl->hOut + st->offPer);
+    const int* hnm = wantTrack ? reinterpret_cast<const int*>(sl->hTrkOut) : nullptr;
+    const int* hmatch = wantTrack ? reinterpret_cast<const int*>(sl->hTrkOut + st->offMatch) : nullptr;
     const int nfr = sl->n;
-    st->pool->parallel_for(nfr, [&](int b) {
-        const int k = hn[b];
-        n_out[b] = k;
-        memcpy(kp_out + b * cap, hkp + b * cap, (size_t)k * sizeof(orbfe_keypoint));
-        memcpy(desc_out + b * cap * ORBFE_DESC_BYTES, hdesc + b * cap * ORBFE_DESC_BYTES, (size_t)k * ORBFE_DESC_BYTES);
-        if (per_level) memcpy(per_level + (size_t)b * nL, hper + (size_t)b * nL, nL * sizeof(int));
-    });
+    {
+        std::lock_guard<std::mutex> pk(st->poolMu);
+        st->pool->parallel_for(nfr, [&](int b) {
+            const int k = hn[b];
+            n_out[b] = k;
+            memcpy(kp_out + b * cap, hkp + b * cap, (size_t)k * sizeof(orbfe_keypoint));
+            memcpy(desc_out + b * cap * ORBFE_DESC_BYTES, hdesc + b * cap * ORBFE_DESC_BYTES, (size_t)k * ORBFE_DESC_BYTES);
+            if (per_level) memcpy(per_level + (size_t)b * nL, hper + (size_t)b * nL, nL * sizeof(int));
+            if (wantTrack) {
+                n_matches[b] = k > 0 ? hnm[b] : 0;
+                memcpy(match_out + b * cap, hmatch + b * cap, (size_t)k * sizeof(int));
+            }
+        });
+    }
     if (n_frames) *n_frames = nfr;
-    st->collected++;
+    st->collected.fetch_add(1, std::memory_order_release);
+    return ORBFE_OK;
+}
+
+int orbfe_stream_collect(orbfe_stream* st, orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, int* n_frames)
+{
+    return stream_collect_impl(st, kp_out, desc_out, n_out, per_level, nullptr, nullptr, n_frames, false);
+}
+
+int orbfe_stream_collect_track(orbfe_stream* st, orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, int* match_out,
+                               int* n_matches, int* n_frames)
+{
+    return stream_collect_impl(st, kp_out, desc_out, n_out, per_level, match_out, n_matches, n_frames, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Map points resident in HBM (orbfe.h: orbfe_map_*)
+// ---------------------------------------------------------------------------------------------
+int orbfe_map_create(orbfe_handle* h, int capacity, orbfe_map** out)
+{
+    if (!h || !out || capacity < 1 || capacity > (1 << 26)) return ORBFE_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    orbfe_map* m = new (std::nothrow) orbfe_map();
+    if (!m) return ORBFE_ERR_OUT_OF_MEMORY;
+    m->h = h;
+    m->cap = capacity;
+    if (hipMalloc(&m->dPts, (size_t)capacity * sizeof(orbfe_world_point)) != hipSuccess ||
+        hipMalloc(&m->dDesc, (size_t)capacity * ORBFE_DESC_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->dPts) (void)hipFree(m->dPts);
+        delete m;
+        h->err = "orbfe_map_create: allocation failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    // an entry that was never written is a bad point: skipped by isInFrustum and by the matcher
+    std::vector<orbfe_world_point> init((size_t)std::min(capacity, 1 << 16));
+    for (auto& p : init) { p = orbfe_world_point{}; p.bad = 1; }
+    for (size_t o = 0; o < (size_t)capacity; o += init.size())
+        if (hipMemcpy(m->dPts + o, init.data(), std::min(init.size(), (size_t)capacity - o) * sizeof(orbfe_world_point),
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(m->dPts);
+            (void)hipFree(m->dDesc);
+            delete m;
+            return ORBFE_ERR_HIP;
+        }
+    (void)hipMemset(m->dDesc, 0, (size_t)capacity * ORBFE_DESC_BYTES);
+    *out = m;
+    return ORBFE_OK;
+}
+
+void orbfe_map_destroy(orbfe_map* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->h->device);
+    (void)hipStreamSynchronize(m->h->stream);
+    if (m->dPts) (void)hipFree(m->dPts);
+    if (m->dDesc) (void)hipFree(m->dDesc);
+    delete m;
+}
+
+int orbfe_map_update(orbfe_handle* h, orbfe_map* m, int n, const int* ids, const orbfe_world_point* points, const uint8_t* desc)
+{
+    if (!h || !m || m->h != h || n < 0 || (n > 0 && (!ids || !points || !desc))) return ORBFE_ERR_INVALID_ARG;
+    for (int i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= m->cap) return ORBFE_ERR_INVALID_ARG;
+    if (n == 0) return ORBFE_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    // staged through the matcher's grow-only arenas: [ids | points | descriptors]; on the handle's stream, i.e. behind
+    // every submission made so far (their kernels run there) and in front of every later one
+    Carver c;
+    const size_t oIds = c.take((size_t)n * sizeof(int));
+    const size_t oPts = c.take((size_t)n * sizeof(orbfe_world_point));
+    const size_t oDesc = c.take((size_t)n * ORBFE_DESC_BYTES);
+    std::string err;
+    MatchScope scope_(h, h->stream);
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
+    int rc = ensure(h->match, c.off, c.off, err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    uint8_t* hp = static_cast<uint8_t*>(h->match.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(h->match.d);
+    memcpy(hp + oIds, ids, (size_t)n * sizeof(int));
+    memcpy(hp + oPts, points, (size_t)n * sizeof(orbfe_world_point));
+    memcpy(hp + oDesc, desc, (size_t)n * ORBFE_DESC_BYTES);
+    HIPCHK(h, hipMemcpyAsync(dp, hp, c.off, hipMemcpyHostToDevice, h->stream));
+    rc = map_scatter_launch(h->stream, n, reinterpret_cast<const int*>(dp + oIds), reinterpret_cast<const orbfe_world_point*>(dp + oPts),
+                            dp + oDesc, m->cap, m->dPts, m->dDesc, err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return ORBFE_OK;
 }
 

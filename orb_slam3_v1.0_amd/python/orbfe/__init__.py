@@ -117,7 +117,8 @@ SYMBOLS = [
     "orbfe_get_device_status", "orbfe_stream_create", "orbfe_stream_destroy", "orbfe_stream_submit", "orbfe_stream_collect",
     "orbfe_stream_collect_view", "orbfe_stream_in_flight", "orbfe_track_frame",
     "orbfe_keyframe_create", "orbfe_keyframe_destroy", "orbfe_keyframe_size", "orbfe_match_triangulation_batch",
-    "orbfe_triangulation_select",
+    "orbfe_triangulation_select", "orbfe_map_create", "orbfe_map_destroy", "orbfe_map_update", "orbfe_stream_enable_track",
+    "orbfe_stream_submit_track", "orbfe_stream_collect_track",
 ]
 
 _lib = None
@@ -170,6 +171,13 @@ def lib():
     L.orbfe_stream_collect.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbfe_stream_collect_view.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbfe_stream_in_flight.argtypes = [vp]
+    L.orbfe_map_create.argtypes = [vp, ci, C.POINTER(vp)]
+    L.orbfe_map_destroy.argtypes = [vp]
+    L.orbfe_map_destroy.restype = None
+    L.orbfe_map_update.argtypes = [vp, vp, ci, vp, vp, vp]
+    L.orbfe_stream_enable_track.argtypes = [vp, vp, ci]
+    L.orbfe_stream_submit_track.argtypes = [vp, vp, ci, ci, C.POINTER(TrackParams), vp, ci, vp]
+    L.orbfe_stream_collect_track.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, sz, ci, ci, vp, vp, vp, vp, vp]
     L.orbfe_get_pyramid_level.argtypes = [vp, ci, ci, ci, vp, ci]
     L.orbfe_debug_get_candidates.argtypes = [vp, ci, ci, vp, ci, vp, vp]
@@ -369,6 +377,31 @@ def make_frame_view(kp, desc, gridCols, gridRows, minX, minY, maxX, maxY, scaleF
     return fv
 
 
+class MapPoints:
+    """orbfe_map: map points resident in HBM (world position, distance range, isBad, Observations, descriptor), indexed
+    by a caller-chosen id in [0, capacity); frames name their local map points by id."""
+
+    def __init__(self, extractor, capacity):
+        self.e, self.L = extractor, extractor.L
+        self.capacity = int(capacity)
+        self.h = C.c_void_p()
+        extractor._chk(self.L.orbfe_map_create(extractor.h, self.capacity, C.byref(self.h)), "orbfe_map_create")
+
+    def update(self, ids, points, desc):
+        ids = np.ascontiguousarray(ids, np.int32)
+        points = np.ascontiguousarray(points, WP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        assert len(ids) == len(points) == len(desc)
+        self.e._chk(self.L.orbfe_map_update(self.e.h, self.h, len(ids), _p(ids), _p(points), _p(desc)), "orbfe_map_update")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_map_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class ExtractStream:
     """orbfe_stream_*: a ring of pinned + device slots; submit() enqueues upload, kernels and download of up to
     `slot_frames` frames without waiting, collect() waits for the oldest submission only."""
@@ -425,6 +458,45 @@ class ExtractStream:
     def collect(self):
         nf, kp, desc, n, per = self.collect_raw()
         return [(kp[b, :n[b]].copy(), desc[b, :n[b]].copy(), per[b].copy()) for b in range(nf)]
+
+    # ---- extract-and-match submissions (orbfe_stream_enable_track / submit_track / collect_track) ----
+    def enable_track(self, map_points, max_points, gridCols, gridRows, minX, minY, maxX, maxY):
+        self.ex._chk(self.L.orbfe_stream_enable_track(self.h, map_points.h, int(max_points)), "orbfe_stream_enable_track")
+        self._map = map_points
+        self._grid = (int(gridCols), int(gridRows), float(minX), float(minY),
+                      float(np.float32(gridCols) / np.float32(np.float32(maxX) - np.float32(minX))),
+                      float(np.float32(gridRows) / np.float32(np.float32(maxY) - np.float32(minY))))
+        self._match = np.full((self.slot_frames, self.ex.cap), -1, np.int32)
+        self._nmatch = np.zeros(self.slot_frames, np.int32)
+
+    def submit_track(self, frames, frusta, ids, th, nnRatio, bFarPoints=False, thFarPoints=0.0, pitch=None):
+        """frames as submit(); frusta: ctypes array (Frustum * n) or list of Frustum; ids: [n][n_points] int32 (id >= 0:
+        entry of the resident map, ~id: the entry with mnLastFrameSeen == current frame, i.e. skipped)."""
+        n = len(frames)
+        if not isinstance(frusta, C.Array):
+            frusta = (Frustum * n)(*frusta)
+        ids = np.ascontiguousarray(ids, np.int32)
+        assert ids.ndim == 2 and ids.shape[0] == n
+        tp = TrackParams()
+        (tp.grid_cols, tp.grid_rows, tp.min_x, tp.min_y, tp.grid_inv_w, tp.grid_inv_h) = self._grid
+        tp.th, tp.nn_ratio, tp.far_points, tp.th_far_points = th, nnRatio, int(bFarPoints), thFarPoints
+        base, stride = frames.ctypes.data, frames.strides[0]
+        ptrs = (C.c_void_p * n)(*[base + b * stride for b in range(n)])
+        rc = self.L.orbfe_stream_submit_track(self.h, ptrs, pitch or frames.strides[1], n, C.byref(tp), frusta, ids.shape[1], _p(ids))
+        if rc == ERR_BUSY:
+            return False
+        self.ex._chk(rc, "orbfe_stream_submit_track")
+        return True
+
+    def collect_track_raw(self):
+        nf = C.c_int()
+        self.ex._chk(self.L.orbfe_stream_collect_track(self.h, _p(self._kp), _p(self._desc), _p(self._n), _p(self._per), _p(self._match),
+                                                       _p(self._nmatch), C.byref(nf)), "orbfe_stream_collect_track")
+        return nf.value, self._kp, self._desc, self._n, self._per, self._match, self._nmatch
+
+    def collect_track(self):
+        nf, kp, desc, n, per, match, nm = self.collect_track_raw()
+        return [(kp[b, :n[b]].copy(), desc[b, :n[b]].copy(), per[b].copy(), match[b, :n[b]].copy(), int(nm[b])) for b in range(nf)]
 
     def collect_view(self):
         """orbfe_stream_collect_view: the oldest submission's results as numpy VIEWS of the slot's pinned block (no
