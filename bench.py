@@ -313,6 +313,72 @@ def host_io_rate(ex, frames, slot_frames, rounds, pinned):
     return done / dt
 
 
+def host_io_match_rate(ex, frames, slot_frames, rounds):
+    """frames/s of extract + isInFrustum + SearchByProjection with HOST pointers in and out through the ring
+    (orbfe_stream_submit_track / collect_track): pinned frames by pointer, every frame's N_MAP_POINTS local map points by id
+    out of a map resident in HBM (orbfe_map_*: world position + descriptor uploaded once, as a SLAM map would be), the
+    frame's own pose (one frustum block per frame).  The map points are the C3 recipe back-projected through the pose, so
+    the matcher sees the same projections / levels / descriptors as in the headline measurement."""
+    import orbfe
+    W, H = ex.W, ex.H
+    n_total, M = len(frames), N_MAP_POINTS
+    res = []
+    for i in range(0, n_total, ex.max_batch):
+        res += ex.extract_batch(list(frames[i:i + ex.max_batch]))
+    F = orbfe.Frustum()
+    F.rcw[0] = F.rcw[4] = F.rcw[8] = 1.0
+    F.min_x, F.max_x, F.min_y, F.max_y = 0.0, float(W), 0.0, float(H)
+    F.fx = F.fy = 458.0
+    F.cx, F.cy, F.mbf = 0.5 * W, 0.5 * H, 40.0
+    F.log_scale_factor, F.n_levels, F.camera_model = float(np.log(np.float32(1.2))), ex.nlevels, 0
+    rng = np.random.default_rng(99)
+    pts = np.zeros((n_total, M), orbfe.WP_DTYPE)
+    mpd = np.zeros((n_total, M, 32), np.uint8)
+    for b, (kp, desc, _) in enumerate(res):
+        mps, mpd[b] = make_map_points(kp, len(kp), desc, M, rng, ex.nlevels, orbfe.MP_DTYPE)
+        z = rng.uniform(2.0, 8.0, M)
+        x, y = (mps["proj_x"] - F.cx) / F.fx * z, (mps["proj_y"] - F.cy) / F.fy * z
+        pts[b]["x"], pts[b]["y"], pts[b]["z"] = x, y, z
+        d = np.sqrt(x * x + y * y + z * z)
+        pts[b]["max_distance"] = d * 1.2 ** (mps["level"] - 0.5)  # PredictScale: ceil(log(max / d) / log 1.2) == level
+        pts[b]["min_distance"] = pts[b]["max_distance"] / 1.2 ** (ex.nlevels - 1)
+        pts[b]["observations"] = mps["observations"]
+    mp = orbfe.MapPoints(ex, n_total * M)
+    mp.update(np.arange(n_total * M), pts.reshape(-1), mpd.reshape(-1, 32))
+    ids = np.arange(n_total * M, dtype=np.int32).reshape(n_total, M)
+    src = torch.from_numpy(frames).pin_memory().numpy()
+    frusta = (orbfe.Frustum * slot_frames)(*([F] * slot_frames))
+    st = ex.stream(slots=3, slot_frames=slot_frames)
+    st.enable_track(mp, M, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H))
+    chunks = [(i, min(slot_frames, n_total - i)) for i in range(0, n_total, slot_frames)]
+    stats = {"matches": 0, "frames": 0}
+
+    def run(n_rounds):
+        done = 0
+        todo = [c for _ in range(n_rounds) for c in chunks]
+        pos = 0
+        while pos < len(todo) or st.in_flight():
+            while pos < len(todo):
+                lo, n = todo[pos]
+                if not st.submit_track(src[lo:lo + n], frusta if n == slot_frames else (orbfe.Frustum * n)(*([F] * n)), ids[lo:lo + n],
+                                       MATCH_TH, MATCH_NN):
+                    break
+                pos += 1
+            nf, _kp, _desc, _n, _per, _match, nm = st.collect_track_raw()
+            stats["matches"] += int(nm[:nf].sum())
+            stats["frames"] += nf
+            done += nf
+        return done
+
+    run(1)
+    t0 = time.perf_counter()
+    done = run(rounds)
+    dt = time.perf_counter() - t0
+    st.close()
+    mp.close()
+    return done / dt, stats["matches"] / max(1, stats["frames"])
+
+
 def launch_ranks(n, argv):
     """`bench.py --gpus N` started as ONE process: start N ranks (one per GPU) through torch.distributed.run on
     127.0.0.1 and relay rank 0's JSON line.  The parent never initialises the GPU (no torch.cuda call, no HIP call): the
@@ -816,8 +882,16 @@ def main():
                 # long enough (>= 0.1 s) that filling and draining the three-slot ring is a few per cent of the timed region
                 out["value_host_io"] = host_io_rate(ex, frames_sets[0], slot, 40, True)
                 out["value_host_io_pageable"] = host_io_rate(ex, frames_sets[0], slot, 20, False)
-                out["host_io"] = {"unit": "frames/s", "what": "extract only, host pointers in (pinned / pageable numpy rows) and out, "
-                                  "ring of 3 slots x %d frames, H2D || kernels || D2H on three streams" % slot,
+                mean_m = None
+                if M:
+                    out["value_host_io_match"], mean_m = host_io_match_rate(ex, frames_sets[0], slot, 20)
+                out["host_io"] = {"unit": "frames/s", "what": "value_host_io / _pageable: extract only, host pointers in (pinned / pageable "
+                                  "numpy rows) and out, ring of 3 slots x %d frames, H2D || kernels || D2H on three streams; "
+                                  "value_host_io_match: the same ring with orbfe_stream_submit_track -- pinned frames by pointer, %d local "
+                                  "map points per frame by id out of a map resident in HBM (orbfe_map_*), the frame's own pose: extract + "
+                                  "isInFrustum + SearchByProjection, keypoints + descriptors + match indices back to host arrays" % (
+                                      slot, N_MAP_POINTS),
+                                  "mean_matches_per_frame_host_io_match": mean_m,
                                   # PCIe Gen5 x16, 63 GB/s per direction, full duplex: the upload (W*H bytes per frame) is the
                                   # larger direction (the ring downloads the padded result block: cap * 56 B per frame)
                                   "pcie_ceiling_frames_per_s": 63e9 / (W * H)}
