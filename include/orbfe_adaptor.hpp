@@ -541,6 +541,91 @@ struct KeyFrameMatcher {
     }
 };
 
+// A key frame's immutable matcher inputs resident on the GPU (orbfe_keyframe_*): create it where the reference constructs
+// the KeyFrame (after ComputeBoW, src/LocalMapping.cc:258), keep it for the key frame's lifetime.  `KF` needs N, mvKeysUn,
+// mFeatVec, mvuRight, mvScaleFactors; descriptors through descOf(pKF).
+class ResidentKeyFrame {
+public:
+    template <class KeyFramePtr, class DescOf>
+    ResidentKeyFrame(orbfe_handle* h, KeyFramePtr pKF, DescOf descOf)
+    {
+        const int n = pKF->N;
+        std::vector<int> node(n > 0 ? n : 1, -1);
+        for (const auto& e : pKF->mFeatVec)
+            for (unsigned i : e.second) node[i] = (int)e.first;  // DBoW2::FeatureVector: node -> features, ascending index
+        std::vector<uint8_t> st(n > 0 ? n : 1, 0);
+        bool anyStereo = false;
+        for (int i = 0; i < n && i < (int)pKF->mvuRight.size(); i++) {
+            st[i] = pKF->mvuRight[i] >= 0 ? 1 : 0;
+            anyStereo = anyStereo || st[i];
+        }
+        orbfe_detail::check(orbfe_keyframe_create(h, n, reinterpret_cast<const orbfe_keypoint*>(pKF->mvKeysUn->data()), descOf(pKF),
+                                                  node.data(), anyStereo ? st.data() : nullptr, pKF->mvScaleFactors.data(),
+                                                  (int)pKF->mvScaleFactors.size(), &kf_), h, "orbfe_keyframe_create");
+    }
+    ~ResidentKeyFrame() { orbfe_keyframe_destroy(kf_); }
+    ResidentKeyFrame(const ResidentKeyFrame&) = delete;
+    ResidentKeyFrame& operator=(const ResidentKeyFrame&) = delete;
+    const orbfe_keyframe* get() const { return kf_; }
+
+private:
+    orbfe_keyframe* kf_ = nullptr;
+};
+
+// The SearchForTriangulation loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:455-488) with ONE GPU launch for
+// all neighbours.  Construct it before the loop (prm[k] = the F12 / epipole / camera block of the pair (pKF1, neighbour
+// k), computed with the reference's own expressions); inside the loop, where the reference calls
+// ORBmatcher::SearchForTriangulation(mpCurrentKeyFrame, pKF2, vMatchedIndices, ...), call Matches(k, pKF1, ...): it takes
+// the map points pKF1 has NOW (those the loop created for earlier neighbours included, :506-509) and returns exactly what
+// the k-th sequential call would return.
+class TriangulationBatch {
+public:
+    template <class KeyFramePtr>
+    TriangulationBatch(orbfe_handle* h, KeyFramePtr pKF1, const ResidentKeyFrame& r1, const std::vector<KeyFramePtr>& vpNeighKFs,
+                       const std::vector<const ResidentKeyFrame*>& r2, const std::vector<orbfe_tri_params>& prm)
+        : n1_(pKF1->N), check_(prm.empty() ? 1 : prm[0].check_orientation)
+    {
+        const int K = (int)vpNeighKFs.size();
+        std::vector<uint8_t> has1(n1_ > 0 ? n1_ : 1);
+        for (int i = 0; i < n1_; i++) has1[i] = pKF1->GetMapPoint(i) ? 1 : 0;
+        std::vector<std::vector<uint8_t>> has2(K);
+        std::vector<const uint8_t*> has2p(K);
+        std::vector<const orbfe_keyframe*> kf2(K);
+        for (int k = 0; k < K; k++) {
+            const int n2 = vpNeighKFs[k]->N;
+            has2[k].resize(n2 > 0 ? n2 : 1);
+            for (int i = 0; i < n2; i++) has2[k][i] = vpNeighKFs[k]->GetMapPoint(i) ? 1 : 0;
+            has2p[k] = has2[k].data();
+            kf2[k] = r2[k]->get();
+        }
+        raw_.assign((size_t)(K > 0 ? K : 1) * (n1_ > 0 ? n1_ : 1), -1);
+        bin_.assign(raw_.size(), 0);
+        orbfe_detail::check(orbfe_match_triangulation_batch(h, r1.get(), has1.data(), K, kf2.data(), has2p.data(), prm.data(), raw_.data(),
+                                                            bin_.data()), h, "orbfe_match_triangulation_batch");
+    }
+
+    template <class KeyFramePtr>
+    int Matches(int k, KeyFramePtr pKF1, std::vector<std::pair<size_t, size_t>>& vMatchedPairs) const
+    {
+        std::vector<uint8_t> now(n1_ > 0 ? n1_ : 1);
+        for (int i = 0; i < n1_; i++) now[i] = pKF1->GetMapPoint(i) ? 1 : 0;
+        std::vector<int> m12(n1_ > 0 ? n1_ : 1);
+        int nmatches = 0;
+        orbfe_detail::check(orbfe_triangulation_select(n1_, raw_.data() + (size_t)k * n1_, bin_.data() + (size_t)k * n1_, now.data(), check_,
+                                                       m12.data(), &nmatches), nullptr, "orbfe_triangulation_select");
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(nmatches);
+        for (int i = 0; i < n1_; i++)
+            if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);  // src/ORBmatcher.cc:664-673
+        return nmatches;
+    }
+
+private:
+    int n1_, check_;
+    std::vector<int> raw_;
+    std::vector<uint8_t> bin_;
+};
+
 // The isInFrustum loop of Tracking::SearchLocalPoints (src/Tracking.cc:1059-1077) for all local map points in one
 // launch.  `frustum` carries what Frame::isInFrustum reads from the frame (GetRcw / GetTcw / GetTwc, image bounds,
 // pinhole intrinsics, mbf, mfLogScaleFactor, mnScaleLevels); `MapPoint` needs GetWorldPos() (indexable [0..2]),

@@ -1,6 +1,7 @@
 // Drives include/orbfe_adaptor.hpp the way src/Frame.cc:178-189 and src/Tracking.cc:1115 drive the
 // reference classes, with light mock Frame / MapPoint types that carry the members those functions read.
 //   usage: test_adaptor <W> <H> <gray.raw> <mps.bin> <M> <out.bin> [<voc.txt> <bow_out.txt> [<world.bin> <M2> <track_out.bin>]]
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -237,6 +238,38 @@ int main(int argc, char** argv)
                                                                [](const std::shared_ptr<KeyFrame>& k) { return k->mDescriptors.data(); });
         size_t self = 0;
         for (auto& pr : pairs) self += pr.first == pr.second;
+        {   // the same pair through resident key frames + the batched entry point (K = 3 copies of the neighbour): every
+            // neighbour's Matches() must equal the sequential call as long as pKF1 gains no map point in between; then
+            // give a few features map points and check that they drop out
+            ResidentKeyFrame rk(ex.handle(), kf, [](const std::shared_ptr<KeyFrame>& k) { return k->mDescriptors.data(); });
+            std::vector<std::shared_ptr<KeyFrame>> neigh{kf, kf, kf};
+            std::vector<const ResidentKeyFrame*> rn{&rk, &rk, &rk};
+            std::vector<orbfe_tri_params> prms{tp, tp, tp};
+            TriangulationBatch tb(ex.handle(), kf, rk, neigh, rn, prms);
+            std::vector<std::pair<size_t, size_t>> p0, p2;
+            const int n0 = tb.Matches(0, kf, p0);
+            int dropped = 0;
+            for (size_t q = 0; q < p0.size() && q < 40; q += 4) {
+                kf->mvpMapPoints[p0[q].first] = std::make_shared<MapPoint3D>();
+                dropped++;
+            }
+            const int n2b = tb.Matches(2, kf, p2);
+            std::vector<std::pair<size_t, size_t>> seq;
+            const int nseq = KeyFrameMatcher::SearchForTriangulation(ex.handle(), kf, kf, tp, seq,
+                                                                     [](const std::shared_ptr<KeyFrame>& k) { return k->mDescriptors.data(); });
+            std::printf("tri_batch first=%d same_first=%d dropped=%d after=%d seq_after=%d same_after=%d\n", n0, (int)(p0 == pairs && n0 == nt),
+                        dropped, n2b, nseq, (int)(p2 == seq));
+            // host cost of one select (n1 features): the replay runs once per neighbour
+            std::vector<uint8_t> nowv(n, 0), binv(n, 3);
+            std::vector<int> rawv(n), outv(n);
+            for (int i = 0; i < n; i++) rawv[i] = i % 3 ? i : -1;
+            int nm2 = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < 2000; r++) orbfe_triangulation_select(n, rawv.data(), binv.data(), nowv.data(), 1, outv.data(), &nm2);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000.0;
+            std::printf("tri_select_us=%.2f n1=%d\n", us, n);
+            kf->mvpMapPoints.assign(n, nullptr);
+        }
         // Fuse: map points sitting exactly on every 5th keypoint (identity pose, pinhole), descriptor copied
         orbfe_frustum fr{};
         fr.rcw[0] = fr.rcw[4] = fr.rcw[8] = 1.0f;

