@@ -56,3 +56,23 @@ def test_create_rejects_bad_arguments(built):
     bad = orbfe.Params(1000, 16000, 1.2, 8, 5, 7, 752, 480, 0, 1)  # iniTh < minTh: unsupported by the fused pass
     assert L.orbfe_create(C.byref(bad), C.byref(h)) == 2
     assert L.orbfe_max_keypoints(None) == 0 and L.orbfe_get_levels(None) == 0
+
+
+def test_shipped_library_reads_no_environment_and_host_only_entries_work(built):
+    """every tuning / diagnostics switch lives in the -DORBFE_DIAG / -DORBFE_ABLATION builds; the
+    shipped library does not even import getenv.  And the host-only half of the batched triangulation
+    (orbfe_triangulation_select) and the versioned parameter blocks work without a GPU."""
+    import subprocess
+    import orbfe
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", orbfe.LIB_PATH]).decode()
+    assert "getenv" not in syms
+    assert orbfe.TriParams().struct_size == C.sizeof(orbfe.TriParams) and orbfe.TrackParams().struct_size == C.sizeof(orbfe.TrackParams)
+    raw = np.array([3, -1, 5, 7, 2, 2], np.int32)
+    rbin = np.array([1, 0, 1, 9, 1, 1], np.uint8)
+    now = np.array([0, 0, 0, 0, 1, 0], np.uint8)
+    n, m = orbfe.triangulation_select(raw, rbin, now, True)  # bin 1 holds 3 matches, bin 9 one (>= 0.1 * 3: kept), feature 4 skipped
+    assert n == 4 and list(m) == [3, -1, 5, 7, -1, 2]
+    n, m = orbfe.triangulation_select(raw, np.array([1, 0, 1, 9, 1, 1] + [], np.uint8), np.zeros(6, np.uint8), False)
+    assert n == 5
+    with pytest.raises(orbfe.OrbfeError):
+        orbfe.triangulation_select(raw, np.full(6, 30, np.uint8), now, True)  # a bin outside the histogram
