@@ -832,13 +832,17 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
             uint32_t k1 = kKey32None, k2 = kKey32None;
             int slot = -1;
             if (c > 0) {
+                // ascending list: the first two free entries are the two smallest free keys -- a running (min, second) over
+                // m = free ? key : none costs v_min_u32 + v_med3_u32 per entry (a <= b: second(a, b, m) = med3(a, m, b))
+                // instead of a compare / select chain; all kTopK claim lookups are issued before the first is used
+                int cl[kTopK];
 #pragma unroll
-                for (int t = 0; t < kTopK; t++) {  // ascending: the first two free entries are the answer
-                    const uint32_t key = keys[t];
-                    if (key != kKey32None && claim[(int)(key & kRankMask)] >= i) {
-                        if (k1 == kKey32None) k1 = key;
-                        else if (k2 == kKey32None) k2 = key;
-                    }
+                for (int t = 0; t < kTopK; t++) cl[t] = claim[keys[t] != kKey32None ? (int)(keys[t] & kRankMask) : 0];
+#pragma unroll
+                for (int t = 0; t < kTopK; t++) {
+                    const uint32_t m = cl[t] >= i ? keys[t] : kKey32None;  // (an empty entry is kKey32None already)
+                    k2 = umed3(k1, m, k2);
+                    k1 = min(k1, m);
                 }
                 if (k2 == kKey32None && c > kTopK) {
                     // The stored list ran dry.  Every candidate that was not stored has a key above
