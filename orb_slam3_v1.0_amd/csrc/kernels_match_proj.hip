@@ -749,6 +749,7 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
 {
     __shared__ ResolveLdsT<N, DESC> S;
     __shared__ int sChanged[2];
+    __shared__ int sGaveUp[2];                           // a claim HOLDER moved away in this sweep (by sweep parity): ranks came free
     __shared__ int sCount;
     __shared__ int sFbCount[2];                          // starved map points of the current sweep (by sweep parity, like sChanged)
     __shared__ int sFbMp[THREADS];
@@ -821,17 +822,32 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
             }
         }
         int res = -1;  // rank of the accepted keypoint
+        // the pair the verdict was made from survives the sweep: a later sweep looks again only if it has to
+        uint32_t k1 = kKey32None, k2 = kKey32None;
+        bool k2StandIn = false;  // k2 is the K-th key standing in for an unseen second best: taken itself, nothing to watch
         // (T[cur] == T[fin] here: initialised above / refilled at the end of the previous chunk)
         for (int iter = 0; iter <= THREADS + 1; iter++) {
             // ---- phase 1: this sweep's tentative claims on top of the final ones ----
-            if (tid == 0) { sChanged[iter & 1] = 0; sFbCount[iter & 1] = 0; }  // last read two barriers ago
+            if (tid == 0) { sChanged[iter & 1] = 0; sFbCount[iter & 1] = 0; sGaveUp[iter & 1] = 0; }  // last read two barriers ago
             if (res >= 0 && obs > 0) atomicMin(&T[cur][res], i);
             __syncthreads();
-            // ---- phase 2: every map point of the chunk looks for its two best free candidates ----
+            // ---- phase 2: the map points whose verdict may have moved look for their two best free candidates ----
+            // T[cur] is rebuilt every sweep from the final claims + every lane's current verdict.  Unless a claim HOLDER
+            // moved away in the previous sweep (sGaveUp), every entry of it is <= the previous sweep's: what was taken
+            // stays taken, so a lane whose best and second best are still free would find the same pair again -- it keeps
+            // its verdict without looking (2 lookups instead of kTopK; a wave whose lanes all keep theirs skips the rest).
             const int* claim = T[cur];
-            uint32_t k1 = kKey32None, k2 = kKey32None;
+            bool look = iter == 0 || sGaveUp[(iter & 1) ^ 1] != 0;
+            if (!look && c > 0) {
+                const int c1 = k1 != kKey32None ? claim[(int)(k1 & kRankMask)] : kClaimFree;
+                const int c2 = (k2 != kKey32None && !k2StandIn) ? claim[(int)(k2 & kRankMask)] : kClaimFree;
+                look = c1 < i || c2 < i;
+            }
             int slot = -1;
-            if (c > 0) {
+            if (c > 0 && look) {
+                k1 = kKey32None;
+                k2 = kKey32None;
+                k2StandIn = false;
                 // ascending list: the first two free entries are the two smallest free keys -- a running (min, second) over
                 // m = free ? key : none costs v_min_u32 + v_med3_u32 per entry (a <= b: second(a, b, m) = med3(a, m, b))
                 // instead of a compare / select chain; all kTopK claim lookups are issued before the first is used
@@ -856,7 +872,10 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
                     else {
                         const int bd = (int)(k1 >> kRankBits);
                         decided = bd > ORBFE_TH_HIGH || (A.nnRatio > 0.f && !((float)bd > A.nnRatio * (float)dK));
-                        if (decided) k2 = keys[kTopK - 1];  // stand-in with distance dK: same verdict as the true second
+                        if (decided) {  // stand-in with distance dK: same verdict as the true second
+                            k2 = keys[kTopK - 1];
+                            k2StandIn = true;
+                        }
                     }
                     if (!decided) {  // exact rescan, done cooperatively below
                         slot = atomicAdd(&sFbCount[iter & 1], 1);
@@ -896,13 +915,15 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
                 }
                 return result;
             };
-            if (slot < 0) {
-                const int result = verdict();
+            // a lane that held the claim on its old rank and now moves away frees that rank: everybody looks again next sweep
+            auto move_to = [&](int result) {
                 if (result != res) {
+                    if (res >= 0 && obs > 0 && claim[res] == i) sGaveUp[iter & 1] = 1;
                     res = result;
                     sChanged[iter & 1] = 1;
                 }
-            }
+            };
+            if (slot < 0 && look && c > 0) move_to(verdict());
             __syncthreads();
             if (sFbCount[iter & 1] > 0) {  // block-uniform, rare: some stored list ran dry undecided -- exact rescan, one wave per map point
                 const int nFb = sFbCount[iter & 1];
@@ -930,11 +951,7 @@ __global__ __launch_bounds__(THREADS) void proj_resolve_kernel(ProjArgs A)
                 if (slot >= 0) {
                     k1 = sFbK1[slot];
                     k2 = sFbK2[slot];
-                    const int result = verdict();
-                    if (result != res) {
-                        res = result;
-                        sChanged[iter & 1] = 1;
-                    }
+                    move_to(verdict());
                 }
                 __syncthreads();
             }
