@@ -38,3 +38,13 @@ def test_random_projection_matching_exact(built):
     rng = np.random.default_rng(4)
     ran = sum(FM.one(rng, k) is not None for k in range(16))
     assert ran >= 12
+
+
+@pytest.mark.gpu
+def test_random_batched_projection_matching_exact(built):
+    """tests/tools/fuzz_batch_match.py: the batched (throughput) kernels of SearchByProjection on random batches, image
+    classes (incl. the hostile look-alike ones), grids, radii, ratios and initial claims; every frame against the oracle."""
+    import fuzz_batch_match as FB
+    rng = np.random.default_rng(6)
+    frames = sum(FB.one(rng, k)[0] for k in range(4))
+    assert frames >= 60
