@@ -305,7 +305,7 @@ def host_io_rate(ex, frames, slot_frames, rounds, pinned):
             done += st.collect_raw()[0]
         return done
 
-    run(1)  # warm: pinned pages touched, kernels loaded
+    run(3)  # warm: every slot of the ring used at least once (its pinned blocks touched and mapped), kernels loaded
     t0 = time.perf_counter()
     done = run(rounds)
     dt = time.perf_counter() - t0
@@ -370,7 +370,7 @@ def host_io_match_rate(ex, frames, slot_frames, rounds):
             done += nf
         return done
 
-    run(1)
+    run(3)  # warm: every slot of the ring used at least once
     t0 = time.perf_counter()
     done = run(rounds)
     dt = time.perf_counter() - t0
