@@ -41,9 +41,16 @@ def test_default_line_has_the_contracted_fields(built):
               "prepare_and_extract_pinned_ms", "prepare_and_extract_oracle_ms"):
         assert lat[k] > 0, k
     assert lat["extract_pinned_ms"] < lat["extract_oracle_ms"]
+    # round 4: the per-frame chain as three calls and as one submission, checked against the oracle inside the bench itself
+    for k in ("project_map_points_ms", "three_calls_ms", "track_frame_ms", "track_frame_pageable_ms", "track_frame_oracle_ms"):
+        assert lat[k] > 0, k
+    assert lat["track_frame_equals_oracle"] is True and lat["track_frame_matches"] > 100
+    assert lat["track_frame_ms"] < lat["track_frame_oracle_ms"]
     cfg = d["config"]
     assert cfg["frames_per_step"] == 48 and cfg["gather"] == "none" and cfg["gather_bytes_per_step"] == 0 and "workload" in cfg
-    assert d["value_host_io"] > 0 and d["value_host_io_pageable"] > 0
+    assert d["value_host_io"] > 0 and d["value_host_io_pageable"] > 0 and d["value_host_io_match"] > 0
+    assert d["host_io"]["mean_matches_per_frame_host_io_match"] > 100  # the ring really matched (map points by id, resident map)
+    assert d["ms_per_step_ranks"]["min"] == d["ms_per_step_ranks"]["max"] == d["ms_per_step"]
 
 
 def test_images_directory_mode(built, tmp_path):
