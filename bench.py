@@ -515,6 +515,19 @@ def latency_block(cfg, device_index, frames, reps=200):
     out["track_frame_pageable_ms"] = _median_ms(fused(pageable), reps)
     got = trk.TrackFrame(pageable[0], Fp, wpts, wdesc, MATCH_TH, MATCH_NN)
     out["track_frame_matches"] = int(got["nmatches"])
+    # the same call with the local map points named by id out of a map resident in HBM (8 KB of ids instead of 128 KB of points)
+    mp_res = orbfe.MapPoints(ex1, N_MAP_POINTS)
+    mp_res.update(np.arange(N_MAP_POINTS), wpts, wdesc)
+    ids_res = np.arange(N_MAP_POINTS, dtype=np.int32)
+    ids_res = np.where(wpts["skip"] != 0, ~ids_res, ids_res).astype(np.int32)  # "mnLastFrameSeen == this frame" travels with the id
+
+    def fused_map():
+        it["i"] += 1
+        return trk.TrackFrameMap(pinned[it["i"] % len(pinned)], Fp, mp_res, ids_res, MATCH_TH, MATCH_NN)
+
+    out["track_frame_map_ms"] = _median_ms(fused_map, reps)
+    got_map = trk.TrackFrameMap(pageable[0], Fp, mp_res, ids_res, MATCH_TH, MATCH_NN)
+    out["track_frame_map_equals_track_frame"] = bool(got_map["nmatches"] == got["nmatches"] and np.array_equal(got_map["match"], got["match"]))
 
     def oracle_chain():
         k, d, _ = ref.extract(pageable[0])
@@ -525,6 +538,7 @@ def latency_block(cfg, device_index, frames, reps=200):
     n_o, match_o = oracle_chain()
     out["track_frame_equals_oracle"] = bool(n_o == got["nmatches"] and np.array_equal(match_o, got["match"]))
     out["track_frame_oracle_ms"] = _median_ms(oracle_chain, 10, 1)
+    mp_res.close()
     # node-side chain at the node's own configuration (mono_inertial_node.cpp:20,59-71): 2048x1536 BGR -> 614x460 grey -> extract
     SW, SH, DW, DH = 2048, 1536, 614, 460
     pcfg = (cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], DW, DH)

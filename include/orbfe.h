@@ -441,6 +441,14 @@ int orbfe_map_update(orbfe_handle *h, orbfe_map *m, int n, const int *ids, const
 /* Gives the ring what it needs to run the whole per-frame chain of orbfe_track_frame per slot: extraction, isInFrustum
  * of the frame's local map points against the frame's own pose, SearchByProjection -- H2D || extract + project + match ||
  * D2H.  max_points = the largest n_points a submission will carry.  Call once, before the first submission. */
+/* orbfe_track_frame with the local map points named by id out of the resident map (ids as orbfe_stream_submit_track:
+ * id >= 0, ~id = skipped for this frame, outside the map = no point): 8 KB instead of 128 KB go up per frame at 2000
+ * points.  mp_out / proj_xr_out / match_out index the id list.  Same results as orbfe_track_frame on the same points. */
+int orbfe_track_frame_map(orbfe_handle *h, const uint8_t *gray, int pitch, const orbfe_frustum *frustum,
+                          const orbfe_track_params *tp, const orbfe_map *map, int n_points, const int *ids,
+                          orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out, int *per_level_counts,
+                          orbfe_map_point *mp_out, float *proj_xr_out, int *match_out, int *n_matches);
+
 int orbfe_stream_enable_track(orbfe_stream *s, orbfe_map *map, int max_points);
 /* orbfe_stream_submit + per frame b: frusta[b] (pose, bounds, camera of THAT frame) and the ids of its n_points local
  * map points, ids[b * n_points + i]: id >= 0 = entry of the resident map; ~id (negative) = the same entry with

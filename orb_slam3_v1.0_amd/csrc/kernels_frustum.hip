@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void frustum_dev_kernel(const orbfe_frustum* _
 __global__ __launch_bounds__(256) void frustum_gather_kernel(const orbfe_frustum* __restrict__ dF, const int* __restrict__ ids, int M,
                                                              int mapCap, const orbfe_world_point* __restrict__ mapPts,
                                                              const uint8_t* __restrict__ mapDesc, orbfe_map_point* __restrict__ out,
-                                                             uint8_t* __restrict__ descOut)
+                                                             uint8_t* __restrict__ descOut, float* __restrict__ projXR)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void frustum_gather_kernel(const orbfe_frustum
         p.bad = 1;
         p.skip = 1;
     }
-    frustum_point(F, 0, &p, out + (size_t)b * M + i, nullptr);
+    frustum_point(F, 0, &p, out + (size_t)b * M + i, projXR ? projXR + (size_t)b * M + i : nullptr);
     uint4* dd = reinterpret_cast<uint4*>(descOut + ((size_t)b * M + i) * 32);
     dd[0] = d0;
     dd[1] = d1;
@@ -177,10 +177,11 @@ int frustum_launch_dev(hipStream_t s, const orbfe_frustum* dF, int n, const orbf
 
 int frustum_gather_launch(hipStream_t s, int B, const orbfe_frustum* dF, const int* dIds, int M, int mapCap,
                           const orbfe_world_point* mapPts, const uint8_t* mapDesc, orbfe_map_point* dOut, uint8_t* dDescOut,
-                          std::string& err)
+                          float* dProjXR, std::string& err)
 {
     if (B == 0 || M == 0) return ORBFE_OK;
-    hipLaunchKernelGGL(frustum_gather_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, dF, dIds, M, mapCap, mapPts, mapDesc, dOut, dDescOut);
+    hipLaunchKernelGGL(frustum_gather_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, dF, dIds, M, mapCap, mapPts, mapDesc, dOut, dDescOut,
+                       dProjXR);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         err = std::string("frustum_gather_kernel: ") + hipGetErrorString(e);

@@ -71,7 +71,7 @@ int frustum_launch_dev(hipStream_t s, const orbfe_frustum* dF, int n, const orbf
 // resident map points (orbfe_map): gather by id + isInFrustum for B frames with their own frusta; scatter of updated entries
 int frustum_gather_launch(hipStream_t s, int B, const orbfe_frustum* dF, const int* dIds, int M, int mapCap,
                           const orbfe_world_point* mapPts, const uint8_t* mapDesc, orbfe_map_point* dOut, uint8_t* dDescOut,
-                          std::string& err);
+                          float* dProjXR, std::string& err);
 int map_scatter_launch(hipStream_t s, int n, const int* dIds, const orbfe_world_point* dPts, const uint8_t* dDesc, int mapCap,
                        orbfe_world_point* mapPts, uint8_t* mapDesc, std::string& err);
 

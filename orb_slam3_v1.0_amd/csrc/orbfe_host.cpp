@@ -105,6 +105,7 @@ struct orbfe_handle {
     struct TrackKey {
         int Mb, inPitch, gridCols, gridRows, farPoints;
         float minX, minY, invW, invH, th, nnRatio, thFar;
+        const void* map;  // null: explicit points in the block; else the resident map the ids refer to (its addresses are in the graph)
     };
     struct TrackGraph {
         TrackKey key;
@@ -749,6 +750,13 @@ int orbfe_extract(orbfe_handle* h, const uint8_t* gray, int pitch, orbfe_keypoin
 // ---------------------------------------------------------------------------------------------
 // orbfe_track_frame: extract -> isInFrustum -> SearchByProjection as one captured hipGraph (orbfe.h)
 // ---------------------------------------------------------------------------------------------
+struct orbfe_map {  // map points resident in HBM (orbfe_map_*, further down)
+    orbfe_handle* h = nullptr;
+    int cap = 0;
+    orbfe_world_point* dPts = nullptr;
+    uint8_t* dDesc = nullptr;
+};
+
 namespace {
 
 // map points per graph: rounded up so that a local map that grows by a few points replays the same graph; the padding
@@ -819,16 +827,21 @@ int track_reserve(orbfe_handle* h, int Mb)
 // the device side of one call, enqueued on s (directly, or under stream capture): extraction chain on the uploaded
 // frame, projection of the uploaded map points with the uploaded frustum, SearchByProjection on the fresh keypoints,
 // download of the result block
-int track_enqueue(orbfe_handle* h, const TrackLayout& L, int Mb, int inPitch, proj::ProjArgs& A, hipStream_t s)
+int track_enqueue(orbfe_handle* h, const TrackLayout& L, int Mb, int inPitch, proj::ProjArgs& A, const orbfe_map* map, hipStream_t s)
 {
     int* dHead = reinterpret_cast<int*>(h->dTrkOut);  // [n, status, n_matches]
     int rc = extract_chain(h, h->dTrkIn, L.inFrame, inPitch, 1, reinterpret_cast<orbfe_keypoint*>(h->dTrkOut + L.oKp),
                            h->dTrkOut + L.oDesc, dHead, reinterpret_cast<int*>(h->dTrkOut + L.oPer), dHead + 1, s);
     if (rc != ORBFE_OK) return rc;
     std::string err;
-    rc = frustum_launch_dev(s, reinterpret_cast<const orbfe_frustum*>(h->dTrkIn + L.oFr), Mb,
-                            reinterpret_cast<const orbfe_world_point*>(h->dTrkIn + L.oPts),
-                            reinterpret_cast<orbfe_map_point*>(h->dTrkOut + L.oMps), reinterpret_cast<float*>(h->dTrkOut + L.oXr), err);
+    const orbfe_frustum* dF = reinterpret_cast<const orbfe_frustum*>(h->dTrkIn + L.oFr);
+    orbfe_map_point* dMps = reinterpret_cast<orbfe_map_point*>(h->dTrkOut + L.oMps);
+    float* dXr = reinterpret_cast<float*>(h->dTrkOut + L.oXr);
+    if (map)  // the block carries ids (at the points' offset): gather record + descriptor from the resident map, then project
+        rc = frustum_gather_launch(s, 1, dF, reinterpret_cast<const int*>(h->dTrkIn + L.oPts), Mb, map->cap, map->dPts, map->dDesc, dMps,
+                                   h->dTrkIn + L.oMpDesc, dXr, err);
+    else
+        rc = frustum_launch_dev(s, dF, Mb, reinterpret_cast<const orbfe_world_point*>(h->dTrkIn + L.oPts), dMps, dXr, err);
     if (rc == ORBFE_OK) rc = proj::proj_launch(s, A, err);
     if (rc != ORBFE_OK) {
         h->err = err;
@@ -840,13 +853,13 @@ int track_enqueue(orbfe_handle* h, const TrackLayout& L, int Mb, int inPitch, pr
 
 }  // namespace
 
-extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch, const orbfe_frustum* frustum,
-                                 const orbfe_track_params* tp, int M, const orbfe_world_point* points, const uint8_t* mp_desc,
-                                 orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, orbfe_map_point* mp_out,
-                                 float* proj_xr_out, int* match_out, int* n_matches)
+static int track_frame_impl(orbfe_handle* h, const uint8_t* gray, int pitch, const orbfe_frustum* frustum,
+                            const orbfe_track_params* tp, int M, const orbfe_world_point* points, const uint8_t* mp_desc,
+                            const orbfe_map* map, const int* ids, orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level,
+                            orbfe_map_point* mp_out, float* proj_xr_out, int* match_out, int* n_matches)
 {
-    if (!h || !gray || !tp || !kp_out || !desc_out || !n_out || !match_out || !n_matches || M < 0 || (M > 0 && (!points || !mp_desc)))
-        return ORBFE_ERR_INVALID_ARG;
+    if (!h || !gray || !tp || !kp_out || !desc_out || !n_out || !match_out || !n_matches || M < 0) return ORBFE_ERR_INVALID_ARG;
+    if (map ? (map->h != h || (M > 0 && !ids)) : (M > 0 && (!points || !mp_desc))) return ORBFE_ERR_INVALID_ARG;
     if (pitch < h->prm.image_width || pitch >= (1 << 24)) return ORBFE_ERR_INVALID_ARG;
     const int rc0 = frustum_validate(frustum);
     if (rc0 != ORBFE_OK) return rc0;
@@ -893,18 +906,26 @@ extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch
         if (before && h->trackMatch.d != before) track_drop_graphs(h);  // the arena moved: graphs hold its old address
     }
 
-    // ---- stage the small block [frustum | points | descriptors], padding records marked bad ----
+    // ---- stage the small block: [frustum | points | descriptors] with the padding records marked bad, or -- resident map --
+    //      [frustum | ids] with the padding ids outside the map (the gather kernel turns those into bad records) ----
     memcpy(h->hTrkIn + L.oFr, frustum, sizeof(orbfe_frustum));
-    if (M) memcpy(h->hTrkIn + L.oPts, points, (size_t)M * sizeof(orbfe_world_point));
-    {
+    size_t smallEnd;  // end of what has to go up behind the frame
+    if (map) {
+        int* hid = reinterpret_cast<int*>(h->hTrkIn + L.oPts);
+        if (M) memcpy(hid, ids, (size_t)M * sizeof(int));
+        for (int i = M; i < Mb; i++) hid[i] = 0x7fffffff;
+        smallEnd = L.oPts + (size_t)Mb * sizeof(int);
+    } else {
+        if (M) memcpy(h->hTrkIn + L.oPts, points, (size_t)M * sizeof(orbfe_world_point));
         orbfe_world_point pad{};
         pad.bad = 1;
         pad.skip = 1;
         orbfe_world_point* hp = reinterpret_cast<orbfe_world_point*>(h->hTrkIn + L.oPts);
         for (int i = M; i < Mb; i++) hp[i] = pad;
+        if (M) memcpy(h->hTrkIn + L.oMpDesc, mp_desc, (size_t)M * ORBFE_DESC_BYTES);
+        if (Mb > M) memset(h->hTrkIn + L.oMpDesc + (size_t)M * ORBFE_DESC_BYTES, 0, (size_t)(Mb - M) * ORBFE_DESC_BYTES);
+        smallEnd = L.inBytes;
     }
-    if (M) memcpy(h->hTrkIn + L.oMpDesc, mp_desc, (size_t)M * ORBFE_DESC_BYTES);
-    if (Mb > M) memset(h->hTrkIn + L.oMpDesc + (size_t)M * ORBFE_DESC_BYTES, 0, (size_t)(Mb - M) * ORBFE_DESC_BYTES);
 
     // ---- upload: pinned frames straight from the caller's buffer + the small block; pageable ones through the
     //      pinned mirror, where frame and small block are ONE copy ----
@@ -920,7 +941,7 @@ extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch
     if (direct) {
         inPitch = pitch;
         HIPCHK(h, hipMemcpyAsync(h->dTrkIn, gray, (size_t)pitch * (H - 1) + (size_t)W, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(h->dTrkIn + L.oFr, h->hTrkIn + L.oFr, L.inBytes - L.oFr, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->dTrkIn + L.oFr, h->hTrkIn + L.oFr, smallEnd - L.oFr, hipMemcpyHostToDevice, s));
     } else {
         if ((pitch & 3) == 0 && pitch <= h->dInPitch) {  // a dword-aligned pitch is kept: the frame is one contiguous copy
             inPitch = pitch;
@@ -929,21 +950,21 @@ extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch
             inPitch = h->dInPitch;
             for (int y = 0; y < H; y++) memcpy(h->hTrkIn + (size_t)y * inPitch, gray + (size_t)y * pitch, (size_t)W);
         }
-        HIPCHK(h, hipMemcpyAsync(h->dTrkIn, h->hTrkIn, L.inBytes, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->dTrkIn, h->hTrkIn, smallEnd, hipMemcpyHostToDevice, s));
     }
 
     // ---- kernels + download: replay the graph of this (bucket, pitch, parameters), capturing it first if needed ----
     bool viaGraph = h->useGraph && !h->timing;
     if (viaGraph) {
         const orbfe_handle::TrackKey key{Mb, inPitch, tp->grid_cols, tp->grid_rows, tp->far_points, tp->min_x, tp->min_y,
-                                         tp->grid_inv_w, tp->grid_inv_h, tp->th, tp->nn_ratio, tp->th_far_points};
+                                         tp->grid_inv_w, tp->grid_inv_h, tp->th, tp->nn_ratio, tp->th_far_points, map};
         hipGraphExec_t exec = nullptr;
         for (auto& g : h->trackGraphs)
             if (memcmp(&g.key, &key, sizeof key) == 0) exec = g.exec;
         if (!exec) {
             hipGraph_t graph = nullptr;
             HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = track_enqueue(h, L, Mb, inPitch, A, s);
+            rc = track_enqueue(h, L, Mb, inPitch, A, map, s);
             const hipError_t ec = hipStreamEndCapture(s, &graph);
             if (rc == ORBFE_OK && ec == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
                 exec = nullptr;
@@ -970,7 +991,7 @@ extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch
         }
     }
     if (!viaGraph) {
-        rc = track_enqueue(h, L, Mb, inPitch, A, s);
+        rc = track_enqueue(h, L, Mb, inPitch, A, map, s);
         if (rc != ORBFE_OK) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(s));
@@ -993,6 +1014,25 @@ extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch
     if (mp_out && M) memcpy(mp_out, h->hTrkOut + L.oMps, (size_t)M * sizeof(orbfe_map_point));
     if (proj_xr_out && M) memcpy(proj_xr_out, h->hTrkOut + L.oXr, (size_t)M * sizeof(float));
     return ORBFE_OK;
+}
+
+extern "C" int orbfe_track_frame(orbfe_handle* h, const uint8_t* gray, int pitch, const orbfe_frustum* frustum,
+                                 const orbfe_track_params* tp, int M, const orbfe_world_point* points, const uint8_t* mp_desc,
+                                 orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, orbfe_map_point* mp_out,
+                                 float* proj_xr_out, int* match_out, int* n_matches)
+{
+    return track_frame_impl(h, gray, pitch, frustum, tp, M, points, mp_desc, nullptr, nullptr, kp_out, desc_out, n_out, per_level, mp_out,
+                            proj_xr_out, match_out, n_matches);
+}
+
+extern "C" int orbfe_track_frame_map(orbfe_handle* h, const uint8_t* gray, int pitch, const orbfe_frustum* frustum,
+                                     const orbfe_track_params* tp, const orbfe_map* map, int M, const int* ids, orbfe_keypoint* kp_out,
+                                     uint8_t* desc_out, int* n_out, int* per_level, orbfe_map_point* mp_out, float* proj_xr_out,
+                                     int* match_out, int* n_matches)
+{
+    if (!map) return ORBFE_ERR_INVALID_ARG;
+    return track_frame_impl(h, gray, pitch, frustum, tp, M, nullptr, nullptr, map, ids, kp_out, desc_out, n_out, per_level, mp_out,
+                            proj_xr_out, match_out, n_matches);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1087,13 +1127,6 @@ struct StreamSlot {
 };
 
 }  // namespace
-
-struct orbfe_map {
-    orbfe_handle* h = nullptr;
-    int cap = 0;
-    orbfe_world_point* dPts = nullptr;
-    uint8_t* dDesc = nullptr;
-};
 
 struct orbfe_stream {
     orbfe_handle* h = nullptr;
@@ -1293,7 +1326,7 @@ static int stream_submit_impl(orbfe_stream* st, const uint8_t* const* grays, int
         uint8_t* dMpDesc = sl.dTrkWork + st->offGatherDesc;
         int rcm = frustum_gather_launch(h->stream, n, reinterpret_cast<const orbfe_frustum*>(sl.dTrkIn),
                                         reinterpret_cast<const int*>(sl.dTrkIn + st->offIds), nPoints, st->map->cap, st->map->dPts,
-                                        st->map->dDesc, dMps, dMpDesc, err);
+                                        st->map->dDesc, dMps, dMpDesc, nullptr, err);
         if (rcm == ORBFE_OK) {
             MatchScope scope_(h, h->stream);
             rcm = scope_.rc;
@@ -1519,8 +1552,10 @@ int orbfe_map_create(orbfe_handle* h, int capacity, orbfe_map** out)
 void orbfe_map_destroy(orbfe_map* m)
 {
     if (!m) return;
+    std::lock_guard<std::mutex> lk(m->h->mu);
     (void)hipSetDevice(m->h->device);
     (void)hipStreamSynchronize(m->h->stream);
+    track_drop_graphs(m->h);  // graphs of orbfe_track_frame_map hold this map's addresses
     if (m->dPts) (void)hipFree(m->dPts);
     if (m->dDesc) (void)hipFree(m->dDesc);
     delete m;

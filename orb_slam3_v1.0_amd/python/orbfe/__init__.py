@@ -118,7 +118,7 @@ SYMBOLS = [
     "orbfe_stream_collect_view", "orbfe_stream_in_flight", "orbfe_track_frame",
     "orbfe_keyframe_create", "orbfe_keyframe_destroy", "orbfe_keyframe_size", "orbfe_match_triangulation_batch",
     "orbfe_triangulation_select", "orbfe_map_create", "orbfe_map_destroy", "orbfe_map_update", "orbfe_stream_enable_track",
-    "orbfe_stream_submit_track", "orbfe_stream_collect_track",
+    "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map",
 ]
 
 _lib = None
@@ -193,6 +193,7 @@ def lib():
     L.orbfe_match_bow_rig.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, cf, ci, vp, vp]
     L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
     L.orbfe_track_frame.argtypes = [vp, vp, ci, C.POINTER(Frustum), C.POINTER(TrackParams), ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orbfe_track_frame_map.argtypes = [vp, vp, ci, C.POINTER(Frustum), C.POINTER(TrackParams), vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
@@ -806,6 +807,29 @@ class FrameTracker:
         e._chk(self.L.orbfe_track_frame(e.h, _p(im), im.strides[0], C.byref(frustum), C.byref(tp), M, _p(points), _p(mpDesc),
                                         _p(kp), _p(desc), C.byref(n), _p(per), _p(mps), _p(xr), _p(match), C.byref(nm)),
                "orbfe_track_frame")
+        k = n.value
+        return dict(kp=kp[:k], desc=desc[:k], per_level=per, mps=mps[:M], proj_xr=xr[:M], match=match[:k], nmatches=nm.value)
+
+    def TrackFrameMap(self, im, frustum, map_points, ids, th, nnRatio, bFarPoints=False, thFarPoints=0.0):
+        """orbfe_track_frame_map: the same chain with the local map points named by id out of a resident MapPoints table
+        (id >= 0, ~id = skipped for this frame, outside the map = no point); match / mps / proj_xr index the id list."""
+        e = self.e
+        im = np.asarray(im)
+        assert im.dtype == np.uint8 and im.shape == (e.H, e.W) and im.strides[1] == 1
+        ids = np.ascontiguousarray(ids, np.int32)
+        M = len(ids)
+        tp = TrackParams()
+        (tp.grid_cols, tp.grid_rows, tp.min_x, tp.min_y, tp.grid_inv_w, tp.grid_inv_h) = self.grid
+        tp.th, tp.nn_ratio, tp.far_points, tp.th_far_points = th, nnRatio, int(bFarPoints), thFarPoints
+        kp = np.zeros(e.cap, KP_DTYPE)
+        desc = np.zeros((e.cap, 32), np.uint8)
+        per = np.zeros(e.nlevels, np.int32)
+        mps = np.zeros(max(M, 1), MP_DTYPE)
+        xr = np.zeros(max(M, 1), np.float32)
+        match = np.full(e.cap, -1, np.int32)
+        n, nm = C.c_int(), C.c_int()
+        e._chk(self.L.orbfe_track_frame_map(e.h, _p(im), im.strides[0], C.byref(frustum), C.byref(tp), map_points.h, M, _p(ids), _p(kp),
+                                            _p(desc), C.byref(n), _p(per), _p(mps), _p(xr), _p(match), C.byref(nm)), "orbfe_track_frame_map")
         k = n.value
         return dict(kp=kp[:k], desc=desc[:k], per_level=per, mps=mps[:M], proj_xr=xr[:M], match=match[:k], nmatches=nm.value)
 

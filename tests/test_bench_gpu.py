@@ -45,6 +45,7 @@ def test_default_line_has_the_contracted_fields(built):
     for k in ("project_map_points_ms", "three_calls_ms", "track_frame_ms", "track_frame_pageable_ms", "track_frame_oracle_ms"):
         assert lat[k] > 0, k
     assert lat["track_frame_equals_oracle"] is True and lat["track_frame_matches"] > 100
+    assert lat["track_frame_map_ms"] > 0 and lat["track_frame_map_equals_track_frame"] is True
     assert lat["track_frame_ms"] < lat["track_frame_oracle_ms"]
     cfg = d["config"]
     assert cfg["frames_per_step"] == 48 and cfg["gather"] == "none" and cfg["gather_bytes_per_step"] == 0 and "workload" in cfg

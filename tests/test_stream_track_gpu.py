@@ -133,9 +133,15 @@ def test_ring_track_equals_oracle_and_track_frame(built, threaded):
         assert kp.tobytes() == kp_r.tobytes() and np.array_equal(desc, desc_r) and np.array_equal(per, per_r), f
         assert nm == n_r and np.array_equal(match, match_r), "frame %d: %d vs %d matches" % (f, nm, n_r)
         total += n_r
-        if f % 9 == 0:  # the single-frame entry point on the same inputs (explicit points instead of ids)
+        if f % 9 == 0:  # the single-frame entry points on the same inputs: explicit points, and ids into the resident map
             one = trk.TrackFrame(frames[f], frusta_p[f], pts_f.view(orbfe.WP_DTYPE), mpd_f, 20.0, 0.85)
             assert one["nmatches"] == nm and np.array_equal(one["match"], match)
+            byid = trk.TrackFrameMap(frames[f], frusta_p[f], mp, ids_all[f], 20.0, 0.85)
+            assert byid["nmatches"] == nm and np.array_equal(byid["match"], match) and byid["kp"].tobytes() == kp_r.tobytes()
+            # (a record whose id is skipped / outside the map carries no point data; everything else is the explicit call's)
+            real = (ids_all[f] >= 0) & (ids_all[f] < cap_map)
+            assert byid["mps"][real].tobytes() == one["mps"][real].tobytes() and byid["proj_xr"][real].tobytes() == one["proj_xr"][real].tobytes()
+            assert (byid["mps"]["in_view"][~real] == 0).all()
     assert total > 100 * n_frames
     st.close()
     mp.close()
