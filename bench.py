@@ -306,11 +306,13 @@ def host_io_rate(ex, frames, slot_frames, rounds, pinned):
         return done
 
     run(3)  # warm: every slot of the ring used at least once (its pinned blocks touched and mapped), kernels loaded
-    t0 = time.perf_counter()
-    done = run(rounds)
-    dt = time.perf_counter() - t0
+    best = 0.0
+    for _ in range(2):  # steady state: the faster of two timed repetitions (the first one on a fresh ring / fresh result arrays
+        t0 = time.perf_counter()  # reads up to 25 % low on some boxes: tools/host_io_order.py)
+        done = run(rounds)
+        best = max(best, done / (time.perf_counter() - t0))
     st.close()
-    return done / dt
+    return best
 
 
 def host_io_match_rate(ex, frames, slot_frames, rounds):
@@ -371,12 +373,14 @@ def host_io_match_rate(ex, frames, slot_frames, rounds):
         return done
 
     run(3)  # warm: every slot of the ring used at least once
-    t0 = time.perf_counter()
-    done = run(rounds)
-    dt = time.perf_counter() - t0
+    best = 0.0
+    for _ in range(2):  # the faster of two timed repetitions, as host_io_rate
+        t0 = time.perf_counter()
+        done = run(rounds)
+        best = max(best, done / (time.perf_counter() - t0))
     st.close()
     mp.close()
-    return done / dt, stats["matches"] / max(1, stats["frames"])
+    return best, stats["matches"] / max(1, stats["frames"])
 
 
 def launch_ranks(n, argv):
