@@ -115,6 +115,27 @@ public:
     }
 #endif
 
+    // Upstream-style call operator (UZ-SLAMLab ORB_SLAM3: ORBextractor::operator()(image, mask, keypoints, descriptors,
+    // vLappingArea)).  This fork has no such member (no referent) -- it is offered for callers
+    // written against upstream and forwards to the same C ABI call.  Returns the number of keypoints.  Keypoints stay in
+    // LEVEL pixels like everywhere in this fork (SPEC DECISION S6) unless toLevel0 is set, which multiplies pt by
+    // mvScaleFactor[octave] as upstream does -- a clearly non-reference convenience.
+    int operator()(const GrayImageView& image, std::vector<KeyPoint>& keypoints, std::vector<uint8_t>& descriptors, bool toLevel0 = false)
+    {
+        auto r = extractFeatures(image);
+        keypoints.clear();
+        descriptors.clear();
+        if (!r) return 0;
+        keypoints = *std::get<0>(*r);
+        descriptors = std::move(std::get<1>(*r));
+        if (toLevel0)
+            for (auto& k : keypoints) {
+                k.pt.x *= mvScaleFactor[k.octave];
+                k.pt.y *= mvScaleFactor[k.octave];
+            }
+        return (int)keypoints.size();
+    }
+
     // include/ORBextractor.h:64-92
     int GetLevels() { return orbfe_get_levels(h_); }
     float GetScaleFactor() { return orbfe_get_scale_factor(h_); }

@@ -99,6 +99,19 @@ int main(int argc, char** argv)
     if (!r) { std::puts("nullopt"); return 2; }
     auto [keys, desc] = *r;
 
+    {   // the upstream-style call operator forwards to the same extraction
+        std::vector<KeyPoint> k2;
+        std::vector<uint8_t> d2;
+        const int n2 = ex(GrayImageView{img.data(), W}, k2, d2);
+        const bool same = n2 == (int)keys->size() && std::memcmp(k2.data(), keys->data(), (size_t)n2 * sizeof(KeyPoint)) == 0 && d2 == desc;
+        std::vector<KeyPoint> k3;
+        std::vector<uint8_t> d3;
+        ex(GrayImageView{img.data(), W}, k3, d3, true);
+        bool scaled = k3.size() == k2.size();
+        const auto sf = ex.GetScaleFactors();
+        for (size_t i = 0; i < k3.size() && scaled; i++) scaled = k3[i].pt.x == k2[i].pt.x * sf[k2[i].octave] && k3[i].pt.y == k2[i].pt.y * sf[k2[i].octave];
+        std::printf("call_operator same=%d scaled=%d\n", (int)same, (int)scaled);
+    }
     auto F = std::make_shared<Frame>();  // Frame::Frame, src/Frame.cc:56-135 (the parts the matcher reads)
     F->mNumKeypoints = (int)keys->size();
     F->mvKeysUn = keys;

@@ -148,6 +148,7 @@ def test_adaptor_matches_oracle(built, tmp_path):
     assert mb and int(mb.group(1)) == nt and mb.group(2) == "1" and mb.group(6) == "1" and int(mb.group(4)) == int(mb.group(5))
     assert int(mb.group(3)) > 0 and int(mb.group(4)) <= nt - int(mb.group(3))  # features that got a map point drop out (:506-509)
     print(re.search(r"tri_select_us=[0-9.]+ n1=\d+", stdout).group(0))
+    assert "call_operator same=1 scaled=1" in stdout  # the upstream-style operator() overload
     assert "prep grey=1 grey2=1 same=1" in stdout  # ImagePreparer with identity maps reproduces the plain extraction
     # SearchBySim3 / Sim3 Fuse / relocalisation SearchByProjection on a key frame seen from its own pose
     ms = re.search(r"sim3 found=(\d+) same=(\d+) fuse3=(\d+) repl=(\d+) added=(\d+) reloc=(\d+) same=(\d+) slot0=(\d+)", stdout)
