@@ -29,8 +29,9 @@ def build_scene(n_frames, pts_per_frame, seed=0):
     frusta_o, frusta_p, pts_all, desc_all, owner = [], [], [], [], []
     for f in range(n_frames):
         Fo, Fp = O.Frustum(), orbfe.Frustum()
-        v = FS.fill_frustum(Fo, ON, W=float(W), H=float(H), n_levels=6, seed=50 + f)
-        FS.fill_frustum(Fp, PN, W=float(W), H=float(H), n_levels=6, seed=50 + f)
+        kb8 = f % 5 == 4  # every fifth frame sees the map through a KannalaBrandt8 camera: per-frame frusta really are per frame
+        v = FS.fill_frustum(Fo, ON, W=float(W), H=float(H), n_levels=6, seed=50 + f, kb8=kb8)
+        FS.fill_frustum(Fp, PN, W=float(W), H=float(H), n_levels=6, seed=50 + f, kb8=kb8)
         kp, desc, _ = eo.extract(frames[f])
         pts, mpd = FS.world_points_on_keypoints(kp, desc, v, pts_per_frame, np.random.default_rng(seed * 1000 + f), 6)
         pts["skip"] = 0
@@ -142,7 +143,7 @@ def test_ring_track_equals_oracle_and_track_frame(built, threaded):
             real = (ids_all[f] >= 0) & (ids_all[f] < cap_map)
             assert byid["mps"][real].tobytes() == one["mps"][real].tobytes() and byid["proj_xr"][real].tobytes() == one["proj_xr"][real].tobytes()
             assert (byid["mps"]["in_view"][~real] == 0).all()
-    assert total > 100 * n_frames
+    assert total > 80 * n_frames
     st.close()
     mp.close()
 

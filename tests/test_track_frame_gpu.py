@@ -48,10 +48,10 @@ def make_oracle(args):
     return O.Extractor(*args)
 
 
-def frusta(seed, W, H, n_levels=8):
+def frusta(seed, W, H, n_levels=8, kb8=False):
     Fo, Fp = O.Frustum(), __import__("orbfe").Frustum()
-    v = FS.fill_frustum(Fo, ON, W=float(W), H=float(H), n_levels=n_levels, seed=seed)
-    FS.fill_frustum(Fp, PN, W=float(W), H=float(H), n_levels=n_levels, seed=seed)
+    v = FS.fill_frustum(Fo, ON, W=float(W), H=float(H), n_levels=n_levels, seed=seed, kb8=kb8)
+    FS.fill_frustum(Fp, PN, W=float(W), H=float(H), n_levels=n_levels, seed=seed, kb8=kb8)
     return Fo, Fp, v
 
 
@@ -70,7 +70,7 @@ def test_track_frame_equals_oracle_chain_on_a_stream(built):
     sizes = [2000, 2010, 1990, 2300, 700, 0, 2000, 5000, 1]
     total = 0
     for i, (img, M) in enumerate(zip(frames, sizes)):
-        Fo, Fp, v = frusta(100 + i, W, H)
+        Fo, Fp, v = frusta(100 + i, W, H, kb8=(i in (3, 6)))  # two frames through the KannalaBrandt8 projection (S5 / S8 sequences)
         kp_r, desc_r, _ = eo.extract(img)
         pts, mpd = _world_points_on_keypoints(kp_r, desc_r, v, max(M, 1), np.random.default_rng(i), 8)
         pts, mpd = pts[:M], mpd[:M]
