@@ -626,6 +626,29 @@ int orbfe_bow_transform(orbfe_handle *h, orbfe_vocab *v, const uint8_t *desc, in
                         int *word_id_out, int *node_id_out, double *weight_out);
 
 /* -------------------------------------------------------------------------------------------
+ * The tracking thread's chain of a frame tracked against its reference key frame, as ONE submission
+ * ---------------------------------------------------------------------------------------- */
+/* replaces, for one frame (Tracking::TrackReferenceKeyFrame, src/Tracking.cc:825-835 -- every frame while the map's IMU
+ * is not initialised, :454-458):
+ *   Frame::Frame -> ExtractORB -> ORBextractor::extractFeatures                    (src/Frame.cc:178-189)
+ *   mCurrentFrame->ComputeBoW(): TemplatedVocabulary::transform per feature        (src/Frame.cc:483-495)
+ *   ORBmatcher::SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches, nnRatio, true)   (src/ORBmatcher.cc:133-327)
+ * gray / pitch / kp_out / desc_out / n_out / per_level_counts as orbfe_extract.  word_id_out / node_id_out / weight_out
+ * (capacity orbfe_max_keypoints(); weight_out may be NULL) as orbfe_bow_transform on the frame's descriptors: the caller
+ * assembles mBowVec / mFeatVec from them.  kf: the reference key frame, resident (orbfe_keyframe_create, whose node_id
+ * came from the same vocabulary and levelsup); kf_has_mp[j] != 0 iff key-frame feature j has a map point that is not bad
+ * as of this call (:182-187), orbfe_keyframe_size(kf) entries.  match_out[i] (capacity orbfe_max_keypoints()) = the
+ * key-frame feature whose map point is written to vpMapPointMatches[i], or -1; n_matches = the return value.
+ * The frame's descriptors never leave the device between extraction, descent and matching; nothing is decided on the
+ * host in between.  Results are byte-identical to orbfe_extract -> orbfe_bow_transform -> orbfe_match_bow with the
+ * FeatureVectors of both sides.  HOST pointers; gray may be pinned (read in place) or pageable. */
+int orbfe_track_reference_keyframe(orbfe_handle *h, const uint8_t *gray, int pitch, const orbfe_vocab *vocab, int levelsup,
+                                   const orbfe_keyframe *kf, const uint8_t *kf_has_mp, float nn_ratio,
+                                   int check_orientation, orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out,
+                                   int *per_level_counts, int *word_id_out, int *node_id_out, double *weight_out,
+                                   int *match_out, int *n_matches);
+
+/* -------------------------------------------------------------------------------------------
  * Misc
  * ---------------------------------------------------------------------------------------- */
 const char *orbfe_status_string(int status);

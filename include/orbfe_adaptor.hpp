@@ -859,6 +859,16 @@ public:
         std::vector<double> w(n);
         orbfe_detail::check(orbfe_bow_transform(h_, v_, desc, n, levelsup, word.data(), node.data(), w.data()), h_,
                             "orbfe_bow_transform");
+        assemble(word.data(), node.data(), w.data(), n, v, fv);
+    }
+
+    // the host half of transform(): BowVector / FeatureVector from the per-feature (word, node, weight) triples, in the
+    // reference's insertion order (TemplatedVocabulary.h:1157-1204), so the doubles are bit-identical
+    template <class BowVector, class FeatureVector>
+    void assemble(const int* word, const int* node, const double* w, int n, BowVector& v, FeatureVector& fv) const
+    {
+        v.clear();
+        fv.clear();
         const bool must = scoring_ != DOT_PRODUCT;  // ScoringObject.h:74-89
         const bool tf = weighting_ == TF || weighting_ == TF_IDF;
         for (int i = 0; i < n; i++) {
@@ -888,12 +898,56 @@ public:
         }
     }
 
+    const orbfe_vocab* get() const { return v_; }
+
 private:
     orbfe_handle* h_;
     orbfe_vocab* v_ = nullptr;
     int k_ = 0, L_ = 0, nWords_ = 0;
     ScoringType scoring_ = L1_NORM;
     WeightingType weighting_ = TF_IDF;
+};
+
+// The tracking thread's chain of a frame tracked against its reference key frame, as ONE submission
+// (orbfe_track_reference_keyframe): what Tracking::GrabImageMonocular + Tracking::TrackReferenceKeyFrame do up to the pose
+// solver -- Frame::Frame -> ExtractORB (src/Frame.cc:178-189), mCurrentFrame->ComputeBoW() (src/Tracking.cc:829,
+// src/Frame.cc:483-495), ORBmatcher::SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches, nnRatio, true) (:835).
+// `resident` is the reference key frame's ResidentKeyFrame (made when the key frame was created); its map points are read
+// as they stand now.  On return `F` carries the fresh keypoints, descriptors (through setDesc(F, rows, n)), mBowVec and
+// mFeatVec; vpMapPointMatches is what SearchByBoW would have filled.  Returns the match count, or -1 when the frame has no
+// keypoints (the reference returns before Track(), src/Tracking.cc:158-159).
+struct ReferenceKeyFrameTracker {
+    template <class FramePtr, class KeyFramePtr, class MapPointPtr, class SetFrameDesc>
+    static int ExtractAndSearchByBoW(ORBextractor& extractor, const GrayImageView& im, FramePtr F, const ORBVocabulary& voc,
+                                     KeyFramePtr pKF, const ResidentKeyFrame& resident, std::vector<MapPointPtr>& vpMapPointMatches,
+                                     const float nnRatio, const bool checkOrientation, SetFrameDesc setDesc, const int levelsup = 4)
+    {
+        orbfe_handle* h = extractor.handle();
+        const int cap = extractor.maxKeypoints();
+        const auto vpMapPointsKF = pKF->GetMapPointMatches();
+        const int nKF = (int)vpMapPointsKF.size();
+        std::vector<uint8_t> hasMP(nKF > 0 ? nKF : 1, 0);
+        for (int i = 0; i < nKF; i++) hasMP[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();  // src/ORBmatcher.cc:182-187
+        auto keys = std::make_shared<std::vector<KeyPoint>>(cap);
+        std::vector<uint8_t> desc((size_t)cap * ORBFE_DESC_BYTES);
+        std::vector<int> word(cap), node(cap), match(cap);
+        std::vector<double> w(cap);
+        int n = 0, nmatches = 0;
+        orbfe_detail::check(orbfe_track_reference_keyframe(h, im.data, im.pitch, voc.get(), levelsup, resident.get(), hasMP.data(), nnRatio,
+                                                           checkOrientation ? 1 : 0, reinterpret_cast<orbfe_keypoint*>(keys->data()),
+                                                           desc.data(), &n, nullptr, word.data(), node.data(), w.data(), match.data(),
+                                                           &nmatches), h, "orbfe_track_reference_keyframe");
+        keys->resize(n);
+        F->mNumKeypoints = n;
+        F->mvKeysUn = keys;
+        setDesc(F, desc.data(), n);
+        voc.assemble(word.data(), node.data(), w.data(), n, F->mBowVec, F->mFeatVec);
+        vpMapPointMatches.assign(n, MapPointPtr());
+        if (n == 0) return -1;
+        for (int i = 0; i < n; i++)
+            if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];  // src/ORBmatcher.cc:241
+        return nmatches;
+    }
 };
 
 }  // namespace ORB_SLAM3

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "keyframe.h"
 #include "match_common.h"
 
 #pragma clang fp contract(off)
@@ -31,31 +32,34 @@ struct BowArgs {
     int* nMatches;   // [1]
 };
 
-__global__ __launch_bounds__(256) void bow_match_kernel(BowArgs A)
+// One vocabulary node shared by key frame and frame (:166-300): the key-frame features kfIdx[k0 .. k1e) of the node in
+// DBoW2 order, sequentially (later ones skip frame features matched by earlier ones, :188); the node's frame features
+// fList[0 .. fCount) scanned by the wave.  IdxT: the frame-side list lives in HBM (CSR from the host) or in LDS (built by
+// the wave from the per-feature node ids); AngKF / AngF: orientation of a key-frame / frame feature.
+template <typename IdxT, typename AngKF, typename AngF>
+__device__ __forceinline__ void bow_walk_node(const int* __restrict__ kfIdx, int k0, int k1e, const IdxT* fList, int fCount,
+                                              const uint8_t* __restrict__ kfDesc, const uint8_t* __restrict__ kfHasMP,
+                                              const uint8_t* __restrict__ fDesc, int nLeftArg, float nnRatio, int checkOrientation,
+                                              int* matchOut, int* binOf, AngKF kfAngle, AngF fAngle, int lane)
 {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (g >= A.G) return;
-    const int k0 = A.kfOff[g], k1e = A.kfOff[g + 1];
-    const int f0 = A.fOff[g], f1 = A.fOff[g + 1];
     const float factor = 1.0f / ORBFE_HISTO_LENGTH;
     for (int iKF = k0; iKF < k1e; iKF++) {  // sequential: later KF features skip matched frame features (:188)
-        const int realIdxKF = A.kfIdx[iKF];
-        if (!A.kfHasMP[realIdxKF]) continue;
+        const int realIdxKF = kfIdx[iKF];
+        if (!kfHasMP[realIdxKF]) continue;
         unsigned long long d4[4];
         {
-            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.kfDesc + (size_t)realIdxKF * 32);
+            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(kfDesc + (size_t)realIdxKF * 32);
             d4[0] = dp[0]; d4[1] = dp[1]; d4[2] = dp[2]; d4[3] = dp[3];
         }
         // two camera sides (F->Nleft != -1, :205-233): separate best / second best for the left and the right features
-        const int nLeft = A.nLeft < 0 ? 0x7fffffff : A.nLeft;
+        const int nLeft = nLeftArg < 0 ? 0x7fffffff : nLeftArg;
         unsigned long long k1 = kKeyNone, k2 = kKeyNone, r1 = kKeyNone, r2 = kKeyNone;
-        for (int iF = f0 + lane; iF < f1; iF += 64) {
-            const int realIdxF = A.fIdx[iF];
-            if (A.matchOut[realIdxF] >= 0) continue;
-            const int dist = hamming256(reinterpret_cast<const uint2*>(A.fDesc + (size_t)realIdxF * 32), d4);
+        for (int iF = lane; iF < fCount; iF += 64) {
+            const int realIdxF = (int)fList[iF];
+            if (matchOut[realIdxF] >= 0) continue;
+            const int dist = hamming256(reinterpret_cast<const uint2*>(fDesc + (size_t)realIdxF * 32), d4);
             if (dist >= 256) continue;
-            const unsigned long long key = ((unsigned long long)dist << 32) | (unsigned)(iF - f0);
+            const unsigned long long key = ((unsigned long long)dist << 32) | (unsigned)iF;
             if (realIdxF < nLeft) {
                 if (key < k1) { k2 = k1; k1 = key; }
                 else if (key < k2) k2 = key;
@@ -65,37 +69,37 @@ __global__ __launch_bounds__(256) void bow_match_kernel(BowArgs A)
             }
         }
         wave_top2(k1, k2);
-        if (A.nLeft >= 0) wave_top2(r1, r2);  // wave-uniform
+        if (nLeftArg >= 0) wave_top2(r1, r2);  // wave-uniform
         if (k1 == kKeyNone) continue;  // bestDist1 == 256 > TH_LOW: neither side is looked at (:237)
         const int bestDist1 = (int)(k1 >> 32);
         const int bestDist2 = k2 == kKeyNone ? 256 : (int)(k2 >> 32);
         if (bestDist1 <= ORBFE_TH_LOW) {  // :237
             bool wrote = false;
-            if ((float)bestDist1 < A.nnRatio * (float)bestDist2) {  // :239
-                const int bestIdxF = A.fIdx[f0 + (int)(k1 & 0xffffffffu)];
+            if ((float)bestDist1 < nnRatio * (float)bestDist2) {  // :239
+                const int bestIdxF = (int)fList[(int)(k1 & 0xffffffffu)];
                 if (lane == 0) {
-                    A.matchOut[bestIdxF] = realIdxKF;
-                    if (A.checkOrientation) {
-                        float rot = A.kfAngle[realIdxKF] - A.fAngle[bestIdxF];
+                    matchOut[bestIdxF] = realIdxKF;
+                    if (checkOrientation) {
+                        float rot = kfAngle(realIdxKF) - fAngle(bestIdxF);
                         if (rot < 0.0) rot = rot + 360.0f;
                         int bin = (int)roundf(rot * factor);
                         if (bin == ORBFE_HISTO_LENGTH) bin = 0;
-                        A.binOf[bestIdxF] = bin;
+                        binOf[bestIdxF] = bin;
                     }
                 }
                 wrote = true;
             }
             // right camera (:263-286): accepted whenever its best distance passes TH_LOW (the ratio test is "|| true")
             if (r1 != kKeyNone && (int)(r1 >> 32) <= ORBFE_TH_LOW) {
-                const int bestIdxFR = A.fIdx[f0 + (int)(r1 & 0xffffffffu)];
+                const int bestIdxFR = (int)fList[(int)(r1 & 0xffffffffu)];
                 if (lane == 0) {
-                    A.matchOut[bestIdxFR] = realIdxKF;
-                    if (A.checkOrientation) {
-                        float rot = A.kfAngle[realIdxKF] - A.fAngle[bestIdxFR];
+                    matchOut[bestIdxFR] = realIdxKF;
+                    if (checkOrientation) {
+                        float rot = kfAngle(realIdxKF) - fAngle(bestIdxFR);
                         if (rot < 0.0) rot = rot + 360.0f;
                         int bin = (int)roundf(rot * factor);
                         if (bin == ORBFE_HISTO_LENGTH) bin = 0;
-                        A.binOf[bestIdxFR] = bin;
+                        binOf[bestIdxFR] = bin;
                     }
                 }
                 wrote = true;
@@ -105,8 +109,19 @@ __global__ __launch_bounds__(256) void bow_match_kernel(BowArgs A)
     }
 }
 
+__global__ __launch_bounds__(256) void bow_match_kernel(BowArgs A)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= A.G) return;
+    const int f0 = A.fOff[g];
+    bow_walk_node(A.kfIdx, A.kfOff[g], A.kfOff[g + 1], A.fIdx + f0, A.fOff[g + 1] - f0, A.kfDesc, A.kfHasMP, A.fDesc, A.nLeft,
+                  A.nnRatio, A.checkOrientation, A.matchOut, A.binOf, [&](int i) { return A.kfAngle[i]; },
+                  [&](int i) { return A.fAngle[i]; }, lane);
+}
+
 // rotation-histogram filter (:304-322) + count; single block
-__global__ __launch_bounds__(256) void bow_finalize_kernel(BowArgs A)
+__device__ __forceinline__ void bow_finalize_block(int* matchOut, const int* binOf, int nF, int checkOrientation, int* nMatches)
 {
     __shared__ int hist[ORBFE_HISTO_LENGTH];
     __shared__ int sInd[3];
@@ -116,15 +131,15 @@ __global__ __launch_bounds__(256) void bow_finalize_kernel(BowArgs A)
     if (tid == 0) sCount = 0;
     __syncthreads();
     int local = 0;
-    for (int j = tid; j < A.nF; j += blockDim.x)
-        if (A.matchOut[j] >= 0) {
+    for (int j = tid; j < nF; j += blockDim.x)
+        if (matchOut[j] >= 0) {
             local++;
-            if (A.checkOrientation) atomicAdd(&hist[A.binOf[j]], 1);
+            if (checkOrientation) atomicAdd(&hist[binOf[j]], 1);
         }
     __syncthreads();
     if (tid == 0) {
         int ind1 = -1, ind2 = -1, ind3 = -1;
-        if (A.checkOrientation) {  // ComputeThreeMaxima :1328-1370
+        if (checkOrientation) {  // ComputeThreeMaxima :1328-1370
             int max1 = 0, max2 = 0, max3 = 0;
             for (int i = 0; i < ORBFE_HISTO_LENGTH; i++) {
                 const int s = hist[i];
@@ -138,19 +153,66 @@ __global__ __launch_bounds__(256) void bow_finalize_kernel(BowArgs A)
         sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
     }
     __syncthreads();
-    if (A.checkOrientation) {
-        for (int j = tid; j < A.nF; j += blockDim.x)
-            if (A.matchOut[j] >= 0) {
-                const int b = A.binOf[j];
+    if (checkOrientation) {
+        for (int j = tid; j < nF; j += blockDim.x)
+            if (matchOut[j] >= 0) {
+                const int b = binOf[j];
                 if (b != sInd[0] && b != sInd[1] && b != sInd[2]) {
-                    A.matchOut[j] = -1;
+                    matchOut[j] = -1;
                     local--;
                 }
             }
     }
     if (local) atomicAdd(&sCount, local);
     __syncthreads();
-    if (tid == 0) *A.nMatches = sCount;
+    if (tid == 0) *nMatches = sCount;
+}
+
+__global__ __launch_bounds__(256) void bow_finalize_kernel(BowArgs A)
+{
+    bow_finalize_block(A.matchOut, A.binOf, A.nF, A.checkOrientation, A.nMatches);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SearchByBoW of the frame the extraction chain has just produced against a key frame resident in HBM
+// (Tracking::TrackReferenceKeyFrame, src/Tracking.cc:825-835): the frame's FeatureVector exists only as the node id of
+// every feature (the vocabulary descent ran a kernel earlier, nothing has been on the host), so the wave of a key-frame
+// node collects the node's frame features itself -- ascending feature index, the order DBoW2 stores them in
+// (TemplatedVocabulary.h:1157-1170) -- into its LDS list and then walks the node exactly like the CSR kernel.
+// A node the frame has no feature in is left after the collection (the lockstep walk of the two FeatureVectors,
+// :150-165, only stops at shared nodes).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bow_track_kernel(BowTrackArgs A)
+{
+    extern __shared__ uint16_t sList[];  // [4 waves][cap]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint16_t* list = sList + (size_t)wave * A.cap;
+    const BowKfRef R = *A.ref;
+    const int nF = min(*A.nF, A.cap);
+    for (int g = blockIdx.x * 4 + wave; g < R.G; g += gridDim.x * 4) {
+        const int nid = R.nodeList[g];
+        int cnt = 0;
+        for (int base = 0; base < nF; base += 64) {
+            const int i = base + lane;
+            const bool hit = i < nF && A.fBow[2 * i + 1] == nid;
+            const unsigned long long m = __ballot(hit);
+            if (hit) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            cnt += __popcll(m);
+        }
+        if (cnt == 0) continue;  // wave-uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bow_walk_node(R.order, R.nodeOff[g], R.nodeOff[g + 1], list, cnt, R.desc, A.kfHasMP, A.fDesc, -1, A.nnRatio,
+                      A.checkOrientation, A.matchOut, A.binOf, [&](int i) { return R.kp[i].angle; },
+                      [&](int i) { return A.fKp[i].angle; }, lane);
+        __builtin_amdgcn_wave_barrier();  // the list is rewritten for the wave's next node
+    }
+}
+
+__global__ __launch_bounds__(256) void bow_track_finalize_kernel(BowTrackArgs A)
+{
+    bow_finalize_block(A.matchOut, A.binOf, min(*A.nF, A.cap), A.checkOrientation, A.nMatches);
 }
 
 }  // namespace
@@ -231,6 +293,21 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
     MCHK(hipStreamSynchronize(s));
     memcpy(matchOut, hMatch, (size_t)nF * sizeof(int));
     *nMatches = *hNM;
+    return ORBFE_OK;
+}
+
+
+int bow_track_launch(hipStream_t s, const BowTrackArgs& A, std::string& err)
+{
+    if (A.cap <= 0 || A.cap > 8192) {  // 16-bit list entries, 4 lists of cap entries in LDS
+        err = "bow_track_launch: frame capacity outside (0, 8192]";
+        return ORBFE_ERR_UNSUPPORTED;
+    }
+    const dim3 blk(256);
+    hipLaunchKernelGGL(fill_kernel, dim3((A.cap + 255) / 256), blk, 0, s, A.matchOut, -1, (size_t)A.cap);
+    hipLaunchKernelGGL(bow_track_kernel, dim3(128), blk, (size_t)4 * A.cap * sizeof(uint16_t), s, A);
+    hipLaunchKernelGGL(bow_track_finalize_kernel, dim3(1), blk, 0, s, A);
+    MCHK(hipGetLastError());
     return ORBFE_OK;
 }
 

@@ -37,4 +37,31 @@ int match_triangulation_batch_run(MatchScratch& m, hipStream_t s, const KeyFrame
                                   const KeyFrameDev* const* kf2, const uint8_t* const* hasMP2, const orbfe_tri_params* P,
                                   int* rawMatch, uint8_t* rawBin, std::string& err);
 
+// SearchByBoW of a frame whose features are still on the device (kernels_match_bow.hip, orbfe_track_reference_keyframe).
+// The key frame is named by a record in device memory, uploaded with the call's inputs, so a captured graph of the chain
+// serves every reference key frame.
+struct BowKfRef {
+    const uint8_t* desc;
+    const orbfe_keypoint* kp;
+    const int* order;
+    const int* nodeList;
+    const int* nodeOff;
+    int G, n;
+};
+struct BowTrackArgs {
+    const BowKfRef* ref;        // device
+    const uint8_t* kfHasMP;     // device [ref->n]: the key-frame feature has a map point that is not bad (:182-187)
+    const orbfe_keypoint* fKp;  // frame keypoints (orientation), descriptors, (word, node) of every feature, count
+    const uint8_t* fDesc;
+    const int* fBow;            // [cap][2]
+    const int* nF;
+    int cap;
+    float nnRatio;
+    int checkOrientation;
+    int* matchOut;              // [cap] key-frame feature matched to frame feature i, -1 = none
+    int* binOf;                 // [cap] scratch
+    int* nMatches;
+};
+int bow_track_launch(hipStream_t s, const BowTrackArgs& A, std::string& err);
+
 }  // namespace orbfe

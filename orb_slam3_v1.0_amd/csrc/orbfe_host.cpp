@@ -118,6 +118,23 @@ struct orbfe_handle {
     uint8_t* hTrkOut = nullptr;  // pinned mirror
     int trkCapM = 0;
     std::vector<TrackGraph> trackGraphs;
+    // orbfe_track_reference_keyframe: extract -> vocabulary descent -> SearchByBoW against a resident key frame.  The key
+    // frame is named by a record inside the input block, so a graph depends only on what is in RefKey.
+    struct RefKey {
+        int inPitch, levelsup, checkOri;
+        float nnRatio;
+        unsigned long long vocabSerial;
+    };
+    struct RefGraph {
+        RefKey key;
+        hipGraphExec_t exec;
+    };
+    uint8_t* dRefIn = nullptr;   // [image | key-frame record | key-frame flags (refCapFlags)]
+    uint8_t* hRefIn = nullptr;
+    uint8_t* dRefOut = nullptr;  // [n, status, n_matches | per-level | keypoints | descriptors | match | (word, node) | leaf | bins]
+    uint8_t* hRefOut = nullptr;
+    int refCapFlags = 0;
+    std::vector<RefGraph> refGraphs;
     std::mutex mu;
     std::string err;
 
@@ -206,6 +223,12 @@ void destroy_impl(orbfe_handle* h)
     for (auto& g : h->trackGraphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     match_scratch_free(h->trackMatch);
+    for (auto& g : h->refGraphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (h->dRefIn) (void)hipFree(h->dRefIn);
+    if (h->dRefOut) (void)hipFree(h->dRefOut);
+    if (h->hRefIn) (void)hipHostFree(h->hRefIn);
+    if (h->hRefOut) (void)hipHostFree(h->hRefOut);
     if (h->dTrkIn) (void)hipFree(h->dTrkIn);
     if (h->dTrkOut) (void)hipFree(h->dTrkOut);
     if (h->hTrkIn) (void)hipHostFree(h->hTrkIn);
@@ -2203,7 +2226,9 @@ int orbfe_prepare_and_extract(orbfe_handle* h, orbfe_prep* p, const uint8_t* bgr
 struct orbfe_vocab {
     orbfe::Vocab* v;
     int device;
+    unsigned long long serial;  // names the vocabulary in graph keys (an address could be reused after a destroy)
 };
+static std::atomic<unsigned long long> g_vocabSerial{1};
 
 int orbfe_vocab_create(orbfe_handle* h, int n_nodes, const int* child_off, const int* child_idx, const uint8_t* node_desc,
                        const int* word_id, const double* weight, int L, orbfe_vocab** out)
@@ -2220,7 +2245,7 @@ int orbfe_vocab_create(orbfe_handle* h, int n_nodes, const int* child_off, const
         h->err = err;
         return rc;
     }
-    *out = new orbfe_vocab{v, h->device};
+    *out = new orbfe_vocab{v, h->device, g_vocabSerial.fetch_add(1)};
     return ORBFE_OK;
 }
 
@@ -2273,3 +2298,226 @@ int orbfe_match_bow(orbfe_handle* h, int G, const int* kf_off, const int* kf_idx
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// orbfe_track_reference_keyframe: extract -> vocabulary descent -> SearchByBoW(resident key frame) as one captured hipGraph
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct RefLayout {
+    size_t inFrame, oRef, oFlags, inBytes;
+    size_t oPer, oKp, oDesc, oMatch, oBow, oLeaf, outBytes /* what is downloaded */, oBin, devBytes;
+};
+
+RefLayout ref_layout(const orbfe_handle* h, int capFlags)
+{
+    RefLayout L{};
+    const size_t cap = (size_t)h->P.kpCapFrame;
+    L.inFrame = align_up((size_t)h->dInPitch * h->prm.image_height, 256);
+    L.oRef = L.inFrame;
+    L.oFlags = L.oRef + align_up(sizeof(BowKfRef), 256);
+    L.inBytes = L.oFlags + align_up((size_t)capFlags, 256);
+    size_t off = 256;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.oPer = take((size_t)h->nLevels * sizeof(int));
+    L.oKp = take(cap * sizeof(orbfe_keypoint));
+    L.oDesc = take(cap * ORBFE_DESC_BYTES);
+    L.oMatch = take(cap * sizeof(int));
+    L.oBow = take(cap * 2 * sizeof(int));
+    L.oLeaf = take(cap * sizeof(int));
+    L.outBytes = off;
+    L.oBin = take(cap * sizeof(int));
+    L.devBytes = off;
+    return L;
+}
+
+void ref_drop_graphs(orbfe_handle* h)
+{
+    for (auto& g : h->refGraphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->refGraphs.clear();
+}
+
+int ref_reserve(orbfe_handle* h, int nFlags)
+{
+    if (h->dRefIn && nFlags <= h->refCapFlags) return ORBFE_OK;
+    ref_drop_graphs(h);
+    if (h->dRefIn) (void)hipFree(h->dRefIn);
+    if (h->dRefOut) (void)hipFree(h->dRefOut);
+    if (h->hRefIn) (void)hipHostFree(h->hRefIn);
+    if (h->hRefOut) (void)hipHostFree(h->hRefOut);
+    h->dRefIn = h->dRefOut = h->hRefIn = h->hRefOut = nullptr;
+    h->refCapFlags = 0;
+    const int capFlags = std::max(4096, nFlags + nFlags / 2);
+    const RefLayout L = ref_layout(h, capFlags);
+    if (hipMalloc(&h->dRefIn, L.inBytes) != hipSuccess || hipMalloc(&h->dRefOut, L.devBytes) != hipSuccess ||
+        hipHostMalloc(&h->hRefIn, L.inBytes) != hipSuccess || hipHostMalloc(&h->hRefOut, L.outBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        h->err = "orbfe_track_reference_keyframe: allocation of the staging blocks failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    h->refCapFlags = capFlags;
+    return ORBFE_OK;
+}
+
+// the device side of one call, enqueued on s (directly, or under stream capture)
+int ref_enqueue(orbfe_handle* h, const RefLayout& L, int inPitch, const orbfe::Vocab* v, int levelsup, float nnRatio, int checkOri,
+                hipStream_t s)
+{
+    const int cap = h->P.kpCapFrame;
+    int* dHead = reinterpret_cast<int*>(h->dRefOut);  // [n, status, n_matches]
+    orbfe_keypoint* dKp = reinterpret_cast<orbfe_keypoint*>(h->dRefOut + L.oKp);
+    int rc = extract_chain(h, h->dRefIn, L.inFrame, inPitch, 1, dKp, h->dRefOut + L.oDesc, dHead, reinterpret_cast<int*>(h->dRefOut + L.oPer),
+                           dHead + 1, s);
+    if (rc != ORBFE_OK) return rc;
+    std::string err;
+    int* dBow = reinterpret_cast<int*>(h->dRefOut + L.oBow);
+    rc = vocab_transform_launch_dev(v, s, h->dRefOut + L.oDesc, dHead, cap, levelsup, dBow, reinterpret_cast<int*>(h->dRefOut + L.oLeaf), err);
+    if (rc == ORBFE_OK) {
+        BowTrackArgs A{};
+        A.ref = reinterpret_cast<const BowKfRef*>(h->dRefIn + L.oRef);
+        A.kfHasMP = h->dRefIn + L.oFlags;
+        A.fKp = dKp;
+        A.fDesc = h->dRefOut + L.oDesc;
+        A.fBow = dBow;
+        A.nF = dHead;
+        A.cap = cap;
+        A.nnRatio = nnRatio;
+        A.checkOrientation = checkOri;
+        A.matchOut = reinterpret_cast<int*>(h->dRefOut + L.oMatch);
+        A.binOf = reinterpret_cast<int*>(h->dRefOut + L.oBin);
+        A.nMatches = dHead + 2;
+        rc = bow_track_launch(s, A, err);
+    }
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->hRefOut, h->dRefOut, L.outBytes, hipMemcpyDeviceToHost, s));
+    return ORBFE_OK;
+}
+
+}  // namespace
+
+extern "C" int orbfe_track_reference_keyframe(orbfe_handle* h, const uint8_t* gray, int pitch, const orbfe_vocab* vocab, int levelsup,
+                                              const orbfe_keyframe* kf, const uint8_t* kf_has_mp, float nn_ratio,
+                                              int check_orientation, orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out,
+                                              int* per_level, int* word_id_out, int* node_id_out, double* weight_out,
+                                              int* match_out, int* n_matches)
+{
+    if (!h || !gray || !vocab || !kf || !kp_out || !desc_out || !n_out || !word_id_out || !node_id_out || !match_out || !n_matches)
+        return ORBFE_ERR_INVALID_ARG;
+    if (pitch < h->prm.image_width || pitch >= (1 << 24)) return ORBFE_ERR_INVALID_ARG;
+    if (vocab->device != h->device || kf->device != h->device) return ORBFE_ERR_INVALID_ARG;
+    const KeyFrameDev* K = kf->k;
+    if (K->n > 0 && !kf_has_mp) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->P.kpCapFrame > 8192) return ORBFE_ERR_UNSUPPORTED;  // 16-bit entries in the matcher's node lists
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;
+    int rc = ref_reserve(h, K->n);
+    if (rc != ORBFE_OK) return rc;
+    const RefLayout L = ref_layout(h, h->refCapFlags);
+
+    // ---- the small block: which key frame (addresses of its resident arrays) + its flags as they stand now ----
+    BowKfRef R{K->desc, K->kp, K->order, K->nodeList, K->nodeOff, K->G, K->n};
+    memcpy(h->hRefIn + L.oRef, &R, sizeof R);
+    if (K->n) memcpy(h->hRefIn + L.oFlags, kf_has_mp, (size_t)K->n);
+    const size_t smallEnd = L.oFlags + (size_t)K->n;
+
+    // ---- upload (as orbfe_track_frame): pinned frames straight from the caller's buffer, pageable ones through the mirror ----
+    bool direct = pitch <= h->dInPitch && (pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(gray) & 3u) == 0;
+    if (direct) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, gray) != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            direct = false;
+        }
+    }
+    int inPitch;
+    if (direct) {
+        inPitch = pitch;
+        HIPCHK(h, hipMemcpyAsync(h->dRefIn, gray, (size_t)pitch * (H - 1) + (size_t)W, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->dRefIn + L.oRef, h->hRefIn + L.oRef, smallEnd - L.oRef, hipMemcpyHostToDevice, s));
+    } else {
+        if ((pitch & 3) == 0 && pitch <= h->dInPitch) {
+            inPitch = pitch;
+            memcpy(h->hRefIn, gray, (size_t)pitch * (H - 1) + (size_t)W);
+        } else {
+            inPitch = h->dInPitch;
+            for (int y = 0; y < H; y++) memcpy(h->hRefIn + (size_t)y * inPitch, gray + (size_t)y * pitch, (size_t)W);
+        }
+        HIPCHK(h, hipMemcpyAsync(h->dRefIn, h->hRefIn, smallEnd, hipMemcpyHostToDevice, s));
+    }
+
+    // ---- kernels + download: replay the graph of this (pitch, vocabulary, parameters), capturing it first if needed ----
+    bool viaGraph = h->useGraph && !h->timing;
+    if (viaGraph) {
+        orbfe_handle::RefKey key;
+        memset(&key, 0, sizeof key);
+        key.inPitch = inPitch; key.levelsup = levelsup; key.checkOri = check_orientation; key.nnRatio = nn_ratio;
+        key.vocabSerial = vocab->serial;
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : h->refGraphs)
+            if (memcmp(&g.key, &key, sizeof key) == 0) exec = g.exec;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = ref_enqueue(h, L, inPitch, vocab->v, levelsup, nn_ratio, check_orientation, s);
+            const hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (rc == ORBFE_OK && ec == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+                exec = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!exec) {
+                (void)hipGetLastError();
+                h->useGraph = false;  // plain launches for the lifetime of the handle
+                viaGraph = false;
+            } else {
+                if (h->refGraphs.size() >= 16) ref_drop_graphs(h);  // vocabularies / parameters cycling: bounded cache
+                h->refGraphs.push_back({key, exec});
+            }
+        }
+        if (viaGraph) {
+            rc = scratch_acquire(h, h->extractUsed, h->extractStream, h->evExtract, s);
+            if (rc != ORBFE_OK) return rc;
+            HIPCHK(h, hipGraphLaunch(exec, s));
+            rc = extract_scratch_release(h, s);
+            if (rc != ORBFE_OK) return rc;
+            h->lastGray = h->dRefIn;
+            h->lastStride = L.inFrame;
+            h->lastPitch = inPitch;
+            h->lastBatch = 1;
+        }
+    }
+    if (!viaGraph) {
+        rc = ref_enqueue(h, L, inPitch, vocab->v, levelsup, nn_ratio, check_orientation, s);
+        if (rc != ORBFE_OK) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+
+    // ---- hand over ----
+    const int* head = reinterpret_cast<const int*>(h->hRefOut);
+    if (head[1]) {
+        char buf[112];
+        snprintf(buf, sizeof buf, "device guard flags 0x%x in orbfe_track_reference_keyframe", (unsigned)head[1]);
+        h->err = buf;
+        return ORBFE_ERR_INTERNAL;
+    }
+    const int n = head[0];
+    *n_out = n;
+    *n_matches = n > 0 ? head[2] : 0;
+    memcpy(kp_out, h->hRefOut + L.oKp, (size_t)n * sizeof(orbfe_keypoint));
+    memcpy(desc_out, h->hRefOut + L.oDesc, (size_t)n * ORBFE_DESC_BYTES);
+    memcpy(match_out, h->hRefOut + L.oMatch, (size_t)n * sizeof(int));
+    if (per_level) memcpy(per_level, h->hRefOut + L.oPer, (size_t)nL * sizeof(int));
+    const int* bow = reinterpret_cast<const int*>(h->hRefOut + L.oBow);
+    const int* leaf = reinterpret_cast<const int*>(h->hRefOut + L.oLeaf);
+    for (int i = 0; i < n; i++) {
+        word_id_out[i] = bow[2 * i];
+        node_id_out[i] = bow[2 * i + 1];
+        if (weight_out) weight_out[i] = vocab->v->hWeight[(size_t)leaf[i]];  // m_nodes[final_id].weight, TemplatedVocabulary.h:1268
+    }
+    return ORBFE_OK;
+}
+

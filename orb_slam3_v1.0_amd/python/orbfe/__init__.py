@@ -118,7 +118,7 @@ SYMBOLS = [
     "orbfe_stream_collect_view", "orbfe_stream_in_flight", "orbfe_track_frame",
     "orbfe_keyframe_create", "orbfe_keyframe_destroy", "orbfe_keyframe_size", "orbfe_match_triangulation_batch",
     "orbfe_triangulation_select", "orbfe_map_create", "orbfe_map_destroy", "orbfe_map_update", "orbfe_stream_enable_track",
-    "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map",
+    "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map", "orbfe_track_reference_keyframe",
 ]
 
 _lib = None
@@ -194,6 +194,7 @@ def lib():
     L.orbfe_match_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), ci, cf, ci, vp, vp]
     L.orbfe_track_frame.argtypes = [vp, vp, ci, C.POINTER(Frustum), C.POINTER(TrackParams), ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_track_frame_map.argtypes = [vp, vp, ci, C.POINTER(Frustum), C.POINTER(TrackParams), vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orbfe_track_reference_keyframe.argtypes = [vp, vp, ci, vp, ci, vp, vp, C.c_float, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
@@ -832,6 +833,30 @@ class FrameTracker:
                                             _p(desc), C.byref(n), _p(per), _p(mps), _p(xr), _p(match), C.byref(nm)), "orbfe_track_frame_map")
         k = n.value
         return dict(kp=kp[:k], desc=desc[:k], per_level=per, mps=mps[:M], proj_xr=xr[:M], match=match[:k], nmatches=nm.value)
+
+    def TrackReferenceKeyFrame(self, im, vocab, levelsup, kf, kfHasMP, nnRatio=0.75, checkOrientation=True):
+        """orbfe_track_reference_keyframe: ExtractORB -> the per-feature part of ComputeBoW -> SearchByBoW(reference key frame,
+        frame) (Tracking::TrackReferenceKeyFrame, src/Tracking.cc:825-835) as one call against a resident KeyFrame ->
+        dict(kp, desc, per_level, word, node, weight, match, nmatches); match[i] = key-frame feature or -1."""
+        e = self.e
+        im = np.asarray(im)
+        assert im.dtype == np.uint8 and im.shape == (e.H, e.W) and im.strides[1] == 1
+        has = np.ascontiguousarray(kfHasMP, np.uint8)
+        assert len(has) == kf.n
+        kp = np.zeros(e.cap, KP_DTYPE)
+        desc = np.zeros((e.cap, 32), np.uint8)
+        per = np.zeros(e.nlevels, np.int32)
+        word = np.zeros(e.cap, np.int32)
+        node = np.zeros(e.cap, np.int32)
+        weight = np.zeros(e.cap, np.float64)
+        match = np.full(e.cap, -1, np.int32)
+        n, nm = C.c_int(), C.c_int()
+        e._chk(self.L.orbfe_track_reference_keyframe(e.h, _p(im), im.strides[0], vocab.v, int(levelsup), kf.h, _p(has), nnRatio,
+                                                     int(checkOrientation), _p(kp), _p(desc), C.byref(n), _p(per), _p(word), _p(node),
+                                                     _p(weight), _p(match), C.byref(nm)), "orbfe_track_reference_keyframe")
+        k = n.value
+        return dict(kp=kp[:k], desc=desc[:k], per_level=per, word=word[:k], node=node[:k], weight=weight[:k], match=match[:k],
+                    nmatches=nm.value)
 
 
 class ImagePreparer:

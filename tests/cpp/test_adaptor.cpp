@@ -75,6 +75,8 @@ struct Frame {
     std::shared_ptr<std::vector<KeyPoint>> mvKeysUn;
     std::vector<uint8_t> mDescriptors;
     std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
+    std::map<unsigned, double> mBowVec;                    // DBoW2::BowVector
+    std::map<unsigned, std::vector<unsigned>> mFeatVec;    // DBoW2::FeatureVector
     std::vector<float> mvScaleFactors;
     float mnMinX = 0, mnMinY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
     int cols = 64, rows = 48;
@@ -163,6 +165,35 @@ int main(int argc, char** argv)
             std::fprintf(fo, "\n");
         }
         fclose(fo);
+        {   // Tracking::TrackReferenceKeyFrame up to the pose solver as ONE submission: this image's own features as the
+            // reference key frame (6 of 7 with a map point); the fused chain must leave the frame with the BoW of transform()
+            // and the matches of ORBmatcher::SearchByBoW on the same FeatureVectors
+            auto kfr = std::make_shared<KeyFrame>();
+            kfr->N = n;
+            kfr->mvKeysUn = keys;
+            kfr->mDescriptors = desc;
+            kfr->mFeatVec = featVec;
+            kfr->mvuRight.assign(n, -1.f);
+            kfr->mvScaleFactors = ex.GetScaleFactors();
+            kfr->mvpMapPoints.resize(n);
+            for (int i = 0; i < n; i++)
+                if (i % 7) kfr->mvpMapPoints[i] = std::make_shared<MapPoint3D>();
+            auto kfDesc = [](const std::shared_ptr<KeyFrame>& k) { return k->mDescriptors.data(); };
+            ResidentKeyFrame rk(ex.handle(), kfr, kfDesc);
+            auto F3 = std::make_shared<Frame>();
+            std::vector<std::shared_ptr<MapPoint3D>> vm, vm2;
+            const int nmR = ReferenceKeyFrameTracker::ExtractAndSearchByBoW(
+                ex, GrayImageView{img.data(), W}, F3, voc, kfr, rk, vm, 0.75f, true,
+                [](const std::shared_ptr<Frame>& f, const uint8_t* rows, int m) { f->mDescriptors.assign(rows, rows + (size_t)m * 32); });
+            const int nmS = ORBmatcher::SearchByBoW(ex.handle(), kfr, F3, vm2, kfr->mFeatVec, F3->mFeatVec, 0.75f, true, kfDesc,
+                                                    [](const std::shared_ptr<Frame>& f) { return f->mDescriptors.data(); });
+            int self = 0;
+            for (int i = 0; i < n && i < (int)vm.size(); i++) self += vm[i] && vm[i] == kfr->mvpMapPoints[i];
+            std::printf("refkf n=%d seq=%d same=%d self=%d bow_same=%d frame_same=%d\n", nmR, nmS, (int)(vm == vm2), self,
+                        (int)(F3->mBowVec == bowVec && F3->mFeatVec == featVec),
+                        (int)(F3->mNumKeypoints == n && F3->mDescriptors == desc &&
+                              std::memcmp(F3->mvKeysUn->data(), keys->data(), (size_t)n * sizeof(KeyPoint)) == 0));
+        }
     }
     if (argc >= 12) {  // the whole per-frame chain through FrameTracker (orbfe_track_frame): frame + local map -> matches
         const auto wraw = slurp(argv[9]);  // M2 x (orbfe_world_point + 32 descriptor bytes + mnLastFrameSeen flag in .skip)

@@ -1,6 +1,7 @@
 """The reference-signature C++ adaptor (include/orbfe_adaptor.hpp): compiles + links without a GPU,
 and on the GPU box reproduces the oracle through the ORBextractor / ORBmatcher classes."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -130,6 +131,11 @@ def test_adaptor_matches_oracle(built, tmp_path):
     assert got_b == list(rb.items())
     got_f = {int(l.split()[0]): [int(t) for t in l.split()[2:]] for l in lines[1 + nb:1 + nb + nf]}
     assert got_f == rf
+    # Tracking::TrackReferenceKeyFrame through ReferenceKeyFrameTracker (orbfe_track_reference_keyframe): == the adaptor's
+    # own sequential SearchByBoW, == the frame transform() leaves, and nearly every flagged feature finds itself
+    mk = re.search(r"refkf n=(\d+) seq=(\d+) same=(\d+) self=(\d+) bow_same=(\d+) frame_same=(\d+)", stdout)
+    assert mk and mk.group(1) == mk.group(2) and mk.group(3) == "1" and mk.group(5) == "1" and mk.group(6) == "1"
+    assert int(mk.group(4)) > 0.7 * len(kp_r) * 6 // 7 and int(mk.group(4)) <= int(mk.group(1))
     # KeyFrameMatcher::SearchForTriangulation (key frame against itself, bCoarse) == the oracle on the same groups
     n_kp = len(kp_r)
     groups = [np.arange(g, n_kp, 50) for g in range(min(50, n_kp))]
@@ -138,7 +144,6 @@ def test_adaptor_matches_oracle(built, tmp_path):
     z8 = np.zeros(n_kp, np.uint8)
     nt, m12 = O.search_for_triangulation(off, idx, off, idx, kp_r, desc_r, z8, None, kp_r, desc_r, z8, None, e.scaleFactors,
                                          np.zeros(9, np.float32), (-1e4, 0.0), False, True, True)
-    import re
     mt = re.search(r"triangulation n=(\d+) self=(\d+) fuse=(\d+) of (\d+)", stdout)
     assert mt and int(mt.group(1)) == nt and int(mt.group(2)) == int((m12 == np.arange(n_kp)).sum())
     assert int(mt.group(3)) > int(mt.group(4)) // 2  # most on-keypoint map points fuse

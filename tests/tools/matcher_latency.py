@@ -183,6 +183,40 @@ def main():
         lambda: voc.transform(feats, 4),
         lambda: O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 6, feats, 4),
         lambda g, c: np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1]))
+    # the chain of a frame tracked against its reference key frame, as one submission and as the three calls it replaces
+    ti = vs.spread_first_level(vs.make_tree(10, 6, seed=17, early_leaf_p=0.02), 18)
+    voci = orbfe.ORBVocabulary(ex, ti["childOff"], ti["childIdx"], ti["nodeDesc"], ti["wordId"], ti["weight"], 6)
+    tv = lambda d: O.vocab_transform(ti["childOff"], ti["childIdx"], ti["nodeDesc"], ti["wordId"], ti["weight"], 6, d, 4)
+    node_kf, node_f = tv(desc)[1], tv(descb)[1]
+    res_kf = orbfe.KeyFrame(ex, kpp, desc, node_kf, sf)
+    has_kf = (np.random.default_rng(4).random(n) < 0.8).astype(np.uint8)
+    shared = sorted(set(node_kf.tolist()) & set(node_f.tolist()))
+    ko, ki, fo, fi = [0], [], [0], []
+    for g in shared:
+        ki += list(np.flatnonzero(node_kf == g)); fi += list(np.flatnonzero(node_f == g))
+        ko.append(len(ki)); fo.append(len(fi))
+    trk = orbfe.FrameTracker(ex, 64, 48, 0.0, 0.0, float(W), float(H))
+    import torch
+    pinned = torch.from_numpy(frames[1].copy()).pin_memory().numpy()
+
+    def ref_three_calls():
+        k2, d2 = ex.extractFeatures(pinned)
+        voci.transform(d2, 4)
+        return m.SearchByBoW(ko, ki, fo, fi, desc, kp["angle"], has_kf, d2, k2["angle"], 0.75, True)
+
+    def ref_oracle():
+        k2, d2, _ = eo.extract(frames[1])
+        tv(d2)
+        return O.search_by_bow(ko, ki, fo, fi, desc, kp["angle"], has_kf, d2, k2["angle"], 0.75, True)
+
+    def ref_fused():
+        r = trk.TrackReferenceKeyFrame(pinned, voci, 4, res_kf, has_kf, 0.75, True)
+        return r["nmatches"], r["match"]
+
+    row("orbfe_track_reference_keyframe", "Tracking.cc:825-835", "N=%d/%d, %d shared nodes, one submission" % (n, len(kpb), len(shared)),
+        ref_fused, ref_oracle, eq2)
+    row("extract + bow_transform + match_bow", "Tracking.cc:825-835", "the same chain as three calls (CSR prebuilt)", ref_three_calls,
+        ref_oracle, eq2)
     if a.json:
         with open(a.json, "w") as f:
             json.dump(dict(host_cpus=os.cpu_count(), reps=a.reps, rows=rows), f, indent=1)

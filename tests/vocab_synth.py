@@ -50,6 +50,22 @@ def make_tree(k=10, L=4, seed=0, early_leaf_p=0.08, dup_p=0.1, stop_p=0.05):
                 weight=weight, parent=np.array(parent, np.int32), depth=np.array(depth, np.int32), nWords=nw)
 
 
+def spread_first_level(t, seed):
+    """moves the first-level subtrees far apart (each XORed with its own random pattern; deeper centres keep their offsets
+    relative to their first-level ancestor), so that the descriptors of an IMAGE -- bits close to uniform -- fall into many
+    nodes, as they do in ORBvoc.txt.  In place; returns the tree."""
+    rng = np.random.default_rng(seed)
+    d = t["nodeDesc"]
+    for c in np.flatnonzero(t["depth"] == 1):
+        delta = rng.integers(0, 256, 32, dtype=np.uint8)
+        stack = [int(c)]
+        while stack:
+            i = stack.pop()
+            d[i] ^= delta
+            stack += [int(x) for x in t["childIdx"][t["childOff"][i]:t["childOff"][i + 1]]]
+    return t
+
+
 def features_near(tree, n, seed=1, noise_bits=20):
     """Descriptors near random tree nodes (so descents spread over the tree) plus pure noise."""
     rng = np.random.default_rng(seed)
