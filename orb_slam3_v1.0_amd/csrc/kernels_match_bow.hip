@@ -182,20 +182,71 @@ __global__ __launch_bounds__(256) void bow_finalize_kernel(BowArgs A)
 // A node the frame has no feature in is left after the collection (the lockstep walk of the two FeatureVectors,
 // :150-165, only stops at shared nodes).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bow_track_kernel(BowTrackArgs A)
+// wave64 minimum with DPP row operations (one VALU instruction per step instead of an LDS permute): quad swaps, row
+// half-mirror and mirror leave every lane of a 16-lane row with the row minimum; row_bcast 15 / 31 fold the rows into lane
+// 63, which is read back as a scalar.  Lanes a row mask leaves out receive the identity.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-    extern __shared__ uint16_t sList[];  // [4 waves][cap]
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint16_t* list = sList + (size_t)wave * A.cap;
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// wave-wide top-2 of per-lane (smallest, second smallest) pairs of 32-bit keys, distinct except for the "none" value:
+// the minimum, then the minimum with its owner's smallest key replaced by that lane's second
+__device__ __forceinline__ void wave_top2_u32(unsigned& k1, unsigned& k2)
+{
+    const unsigned m1 = wave_min_u32(k1);
+    const unsigned m2 = wave_min_u32(k1 == m1 ? k2 : k1);
+    k1 = m1;
+    k2 = m2;
+}
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// One wave per block, one vocabulary node of the key frame at a time.  The node ids of the frame's features are staged in
+// LDS once per block.  For a node the wave gathers the frame side -- descriptors and orientations: the first 64 features in
+// registers, the rest in LDS (two 16-byte halves, each its own array: conflict-free b128 reads); "matched" as a bit per
+// feature in its owning lane --, loads the key-frame side 64 features at a time into registers (lane l holds feature l of
+// the chunk) and walks it sequentially: one descriptor broadcast per step (readlane), distances, a DPP wave top-2.  No
+// step of the walk waits on HBM, and for a node of <= 64 frame features none touches LDS.  (Computing every feature's two
+// best candidates up front and replaying the order with scalar steps was measured: 220 us per call against 206 -- in a
+// node where most features get matched a later feature has nearly always lost one of its two.)  Nodes with more than
+// kBowNodeCap frame features (degenerate vocabularies: levelsup >= L puts a whole frame into one node) take the general walk.
+constexpr int kBowNodeCap = 512;
+
+__global__ __launch_bounds__(64) void bow_track_kernel(BowTrackArgs A)
+{
+    extern __shared__ uint4 sMem4[];
+    const int lane = threadIdx.x;
+    uint4* sLo = sMem4;
+    uint4* sHi = sLo + kBowNodeCap;
+    float* sAng = reinterpret_cast<float*>(sHi + kBowNodeCap);
+    int* sNode = reinterpret_cast<int*>(sAng + kBowNodeCap);                    // [cap] node of every frame feature
+    uint16_t* list = reinterpret_cast<uint16_t*>(sNode + A.cap);                // [cap] frame features of the current node
     const BowKfRef R = *A.ref;
+    if ((int)blockIdx.x >= R.G) return;
     const int nF = min(*A.nF, A.cap);
-    for (int g = blockIdx.x * 4 + wave; g < R.G; g += gridDim.x * 4) {
+    for (int i = lane; i < nF; i += 64) sNode[i] = A.fBow[2 * i + 1];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr unsigned kNone = 0xffffffffu;
+    for (int g = blockIdx.x; g < R.G; g += gridDim.x) {
         const int nid = R.nodeList[g];
+        const int k0 = R.nodeOff[g], cntK = R.nodeOff[g + 1] - k0;
         int cnt = 0;
         for (int base = 0; base < nF; base += 64) {
             const int i = base + lane;
-            const bool hit = i < nF && A.fBow[2 * i + 1] == nid;
+            const bool hit = i < nF && sNode[i] == nid;
             const unsigned long long m = __ballot(hit);
             if (hit) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
             cnt += __popcll(m);
@@ -203,10 +254,80 @@ __global__ __launch_bounds__(256) void bow_track_kernel(BowTrackArgs A)
         if (cnt == 0) continue;  // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        bow_walk_node(R.order, R.nodeOff[g], R.nodeOff[g + 1], list, cnt, R.desc, A.kfHasMP, A.fDesc, -1, A.nnRatio,
-                      A.checkOrientation, A.matchOut, A.binOf, [&](int i) { return R.kp[i].angle; },
-                      [&](int i) { return A.fKp[i].angle; }, lane);
-        __builtin_amdgcn_wave_barrier();  // the list is rewritten for the wave's next node
+        if (cnt <= kBowNodeCap) {
+            // frame side: the first 64 features of the node in registers (lane l holds list position l), the rest in LDS;
+            // "matched" as one bit per 64-feature chunk in the owning lane (position p belongs to lane p & 63)
+            uint4 lo0 = make_uint4(0, 0, 0, 0), hi0 = lo0;
+            float ang0 = 0.f;
+            int idx0 = 0;
+            for (int p = lane; p < cnt; p += 64) {
+                const int f = (int)list[p];
+                const uint4* dp = reinterpret_cast<const uint4*>(A.fDesc + (size_t)f * 32);
+                const uint4 lo = dp[0], hi = dp[1];
+                const float ang = A.fKp[f].angle;
+                if (p < 64) { lo0 = lo; hi0 = hi; ang0 = ang; idx0 = f; }
+                else { sLo[p] = lo; sHi[p] = hi; sAng[p] = ang; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            unsigned taken = 0;  // bit c: list position c * 64 + lane is matched
+            for (int kc = 0; kc < cntK; kc += 64) {
+                const int nk = min(64, cntK - kc);
+                const bool kOn = lane < nk;
+                const int myK = kOn ? R.order[k0 + kc + lane] : 0;
+                unsigned long long kd[4] = {0, 0, 0, 0};
+                float kAng = 0.f;
+                int kHas = 0;
+                if (kOn) {
+                    const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(R.desc + (size_t)myK * 32);
+                    kd[0] = dp[0]; kd[1] = dp[1]; kd[2] = dp[2]; kd[3] = dp[3];
+                    kAng = R.kp[myK].angle;
+                    kHas = A.kfHasMP[myK];
+                }
+                for (int j = 0; j < nk; j++) {  // sequential: later KF features skip matched frame features (:188)
+                    if (!__builtin_amdgcn_readlane(kHas, j)) continue;
+                    const unsigned long long d0 = readlane_u64(kd[0], j), d1 = readlane_u64(kd[1], j), d2 = readlane_u64(kd[2], j),
+                                             d3 = readlane_u64(kd[3], j);
+                    unsigned k1 = kNone, k2 = kNone;
+                    for (int p = lane, c = 0; p < cnt; p += 64, c++) {
+                        if ((taken >> c) & 1u) continue;
+                        const uint4 lo = c == 0 ? lo0 : sLo[p], hi = c == 0 ? hi0 : sHi[p];
+                        const int dist = __popcll((((unsigned long long)lo.y << 32) | lo.x) ^ d0) + __popcll((((unsigned long long)lo.w << 32) | lo.z) ^ d1) +
+                                         __popcll((((unsigned long long)hi.y << 32) | hi.x) ^ d2) + __popcll((((unsigned long long)hi.w << 32) | hi.z) ^ d3);
+                        if (dist >= 256) continue;
+                        const unsigned key = ((unsigned)dist << 16) | (unsigned)p;  // (distance, position in the node's list)
+                        if (key < k1) { k2 = k1; k1 = key; }
+                        else if (key < k2) k2 = key;
+                    }
+                    wave_top2_u32(k1, k2);
+                    if (k1 == kNone) continue;  // bestDist1 == 256 > TH_LOW (:237)
+                    const int bestDist1 = (int)(k1 >> 16);
+                    const int bestDist2 = k2 == kNone ? 256 : (int)(k2 >> 16);
+                    if (bestDist1 <= ORBFE_TH_LOW && (float)bestDist1 < A.nnRatio * (float)bestDist2) {  // :237-239
+                        const int realIdxKF = __builtin_amdgcn_readlane(myK, j);
+                        const float angKF = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kAng), j));
+                        const int pos = (int)(k1 & 0xffffu);
+                        if (lane == (pos & 63)) {  // the owner of the position
+                            const int c = pos >> 6;
+                            taken |= 1u << c;
+                            const int bestIdxF = c == 0 ? idx0 : (int)list[pos];
+                            A.matchOut[bestIdxF] = realIdxKF;
+                            if (A.checkOrientation) {
+                                float rot = angKF - (c == 0 ? ang0 : sAng[pos]);
+                                if (rot < 0.0) rot = rot + 360.0f;
+                                int bin = (int)roundf(rot * (1.0f / ORBFE_HISTO_LENGTH));
+                                if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+                                A.binOf[bestIdxF] = bin;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            bow_walk_node(R.order, k0, k0 + cntK, list, cnt, R.desc, A.kfHasMP, A.fDesc, -1, A.nnRatio, A.checkOrientation,
+                          A.matchOut, A.binOf, [&](int i) { return R.kp[i].angle; }, [&](int i) { return A.fKp[i].angle; }, lane);
+        }
+        __builtin_amdgcn_wave_barrier();  // the LDS arrays are rewritten for the block's next node
     }
 }
 
@@ -299,13 +420,14 @@ int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const
 
 int bow_track_launch(hipStream_t s, const BowTrackArgs& A, std::string& err)
 {
-    if (A.cap <= 0 || A.cap > 8192) {  // 16-bit list entries, 4 lists of cap entries in LDS
-        err = "bow_track_launch: frame capacity outside (0, 8192]";
+    if (A.cap <= 0 || A.cap > 7168) {  // 16-bit list entries; node ids + one list of cap entries in LDS (<= 61 KB)
+        err = "bow_track_launch: frame capacity outside (0, 7168]";
         return ORBFE_ERR_UNSUPPORTED;
     }
     const dim3 blk(256);
     hipLaunchKernelGGL(fill_kernel, dim3((A.cap + 255) / 256), blk, 0, s, A.matchOut, -1, (size_t)A.cap);
-    hipLaunchKernelGGL(bow_track_kernel, dim3(128), blk, (size_t)4 * A.cap * sizeof(uint16_t), s, A);
+    const size_t lds = (size_t)kBowNodeCap * (2 * sizeof(uint4) + sizeof(float)) + (size_t)A.cap * (sizeof(int) + sizeof(uint16_t));
+    hipLaunchKernelGGL(bow_track_kernel, dim3(512), dim3(64), lds, s, A);
     hipLaunchKernelGGL(bow_track_finalize_kernel, dim3(1), blk, 0, s, A);
     MCHK(hipGetLastError());
     return ORBFE_OK;

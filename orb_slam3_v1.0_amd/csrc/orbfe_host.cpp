@@ -2412,7 +2412,7 @@ extern "C" int orbfe_track_reference_keyframe(orbfe_handle* h, const uint8_t* gr
     const KeyFrameDev* K = kf->k;
     if (K->n > 0 && !kf_has_mp) return ORBFE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (h->P.kpCapFrame > 8192) return ORBFE_ERR_UNSUPPORTED;  // 16-bit entries in the matcher's node lists
+    if (h->P.kpCapFrame > 7168) return ORBFE_ERR_UNSUPPORTED;  // the matcher's per-frame LDS arrays (bow_track_launch)
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;

@@ -58,11 +58,12 @@ def make_kf(eo, t, levelsup, img):
     return dict(kp=kp, desc=desc, node=node.astype(np.int32))
 
 
-@pytest.mark.parametrize("k,L,levelsup", [(10, 5, 3), (10, 6, 4), (6, 4, 1)])
+@pytest.mark.parametrize("k,L,levelsup", [(10, 5, 3), (10, 6, 4), (6, 4, 1), (6, 4, 4)])
 def test_chain_equals_oracle_on_a_stream(built, k, L, levelsup):
     """consecutive frames of one stream against a reference key frame that changes twice on the way (the graph of the chain
     does not depend on the key frame), flags that change from frame to frame, pageable / pinned / padded sources, both
-    settings of checkOrientation, two ratios."""
+    settings of checkOrientation, two ratios.  (6, 4, 4): levelsup == L, the whole frame in one node -- the matcher's
+    general walk; (6, 4, 1): ~200 nodes of a few features; the others ~100 nodes, some of them with more than 64 features."""
     import torch
     import orbfe
     from orbfe import synth

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""The fused per-frame chain (orbfe_track_frame) in a loop, for `rocprofv3 --kernel-trace --stats`: per-kernel durations at
-batch 1 and -- with `--report DIR` on the trace's kernel CSV -- the timeline of one call (kernel start / end relative to the
-call's first kernel, gaps between kernels)."""
+"""The fused per-frame chains (orbfe_track_frame; with `ref` as first argument orbfe_track_reference_keyframe) in a loop, for
+`rocprofv3 --kernel-trace --stats`: per-kernel durations at batch 1 and -- with `--report DIR [last-kernel]` on the trace's
+kernel CSV -- the timeline of one call (kernel start / end relative to the call's first kernel, gaps between kernels)."""
 import csv
 import glob
 import os
@@ -14,12 +14,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
 
 
-def report(d):
+def report(d, last="proj_resolve"):
     f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # one call = the dispatches from one memset-following pyramid kernel to the resolve kernel; take the LAST complete call
-    ends = [i for i, r in enumerate(rows) if "proj_resolve" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if last in r["Kernel_Name"]]
     if len(ends) < 2:
         raise SystemExit("no complete call in the trace")
     lo, hi = ends[-2] + 1, ends[-1]
@@ -37,7 +37,7 @@ def report(d):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--report":
-        report(sys.argv[2])
+        report(sys.argv[2], *sys.argv[3:4])
         sys.exit(0)
     import numpy as np
     import torch
@@ -47,11 +47,28 @@ if __name__ == "__main__":
     from orbfe import synth
     cfg = bench.WORKLOADS["euroc_752x480"]
     W, H = cfg[6], cfg[7]
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_MAP_POINTS
     ex = orbfe.ORBextractor(*cfg, device=0, max_batch=1)
     trk = orbfe.FrameTracker(ex, bench.GRID[0], bench.GRID[1], 0.0, 0.0, float(W), float(H))
     frames = [torch.from_numpy(f.copy()).pin_memory().numpy() for f in synth.stream(W, H, 16)]
     kp, desc = ex.extractFeatures(frames[0])
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":  # the chain against the reference key frame (frame 0), vocabulary k=10 L=5
+        import vocab_synth as vs
+        t = vs.spread_first_level(vs.make_tree(10, 5, seed=17, early_leaf_p=0.02), 18)
+        voc = orbfe.ORBVocabulary(ex, t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 5)
+        _, node, _ = voc.transform(desc, 3)
+        kf = orbfe.KeyFrame(ex, kp, desc, node, ex.mvScaleFactor)
+        has = np.ones(len(kp), np.uint8)
+        for i in range(10):
+            trk.TrackReferenceKeyFrame(frames[i % 16], voc, 3, kf, has)
+        ts = []
+        for i in range(100):
+            t0 = time.perf_counter()
+            r = trk.TrackReferenceKeyFrame(frames[i % 16], voc, 3, kf, has)
+            ts.append(time.perf_counter() - t0)
+        print("orbfe_track_reference_keyframe: median %.1f us, min %.1f us per call, %d nodes in the key frame, %d keypoints, %d matches" % (
+            np.median(ts) * 1e6, min(ts) * 1e6, len(set(node.tolist())), len(r["kp"]), r["nmatches"]))
+        sys.exit(0)
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_MAP_POINTS
     Fp = orbfe.Frustum()
     names = {k: k for k in ("rcw", "tcw", "twc", "min_x", "max_x", "min_y", "max_y", "fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4",
                             "mbf", "log_scale_factor", "n_levels", "camera_model")}
