@@ -48,3 +48,14 @@ def test_random_batched_projection_matching_exact(built):
     rng = np.random.default_rng(6)
     frames = sum(FB.one(rng, k)[0] for k in range(4))
     assert frames >= 60
+
+
+@pytest.mark.gpu
+def test_random_reference_keyframe_chains_exact(built):
+    """tests/tools/fuzz_ref_keyframe.py: orbfe_track_reference_keyframe on random geometries, image classes, vocabulary shapes
+    (one node ... hundreds), key frames (same scene / same image / another scene, shuffled, bits flipped, features outside the
+    FeatureVector), flags, ratios; every field against the oracle's chain."""
+    import fuzz_ref_keyframe as FR
+    rng = np.random.default_rng(8)
+    tot = [FR.one(rng, k) for k in range(14)]
+    assert sum(m for _, m in tot) > 500
