@@ -83,6 +83,43 @@ int main(int argc, char** argv)
     const bool same = nm == nm2 && std::memcmp(match.data(), match2.data(), (size_t)n * sizeof(int)) == 0;
     std::printf("c_abi_latency_us extract=%.1f track_frame=%.1f track_frame_map=%.1f keypoints=%d matches=%d same=%d rc=%d reps=%d\n", e, t, tm, n,
                 nm, (int)same, rc, reps);
+    if (argc > 8) {  // the chain against the reference key frame: vocabulary from a binary dump, the frame's own features as key frame
+        const auto vraw = slurp(argv[8]);  // int32 [nNodes, nEdges, L, levelsup] | childOff | childIdx | wordId | nodeDesc (32 B rows) | weight (f64)
+        const int* hd = reinterpret_cast<const int*>(vraw.data());
+        const int nNodes = hd[0], nEdges = hd[1], L = hd[2], levelsup = hd[3];
+        const int* childOff = hd + 4;
+        const int* childIdx = childOff + nNodes + 1;
+        const int* wordId = childIdx + nEdges;
+        const uint8_t* nodeDesc = reinterpret_cast<const uint8_t*>(wordId + nNodes);
+        std::vector<double> weight((size_t)nNodes);
+        std::memcpy(weight.data(), nodeDesc + (size_t)nNodes * 32, (size_t)nNodes * sizeof(double));
+        orbfe_vocab* voc = nullptr;
+        if (orbfe_vocab_create(h, nNodes, childOff, childIdx, nodeDesc, wordId, weight.data(), L, &voc) != ORBFE_OK) return 7;
+        rc |= orbfe_extract(h, img.data(), W, kp.data(), desc.data(), &n, nullptr);
+        std::vector<int> word((size_t)cap), node((size_t)cap), matchR((size_t)cap);
+        std::vector<double> w((size_t)cap);
+        rc |= orbfe_bow_transform(h, voc, desc.data(), n, levelsup, word.data(), node.data(), w.data());
+        std::vector<float> sf(8);
+        {
+            float s = 1.f;
+            for (int i = 0; i < 8; i++) { sf[(size_t)i] = s; s *= 1.2f; }
+        }
+        orbfe_keyframe* kf = nullptr;
+        if (orbfe_keyframe_create(h, n, kp.data(), desc.data(), node.data(), nullptr, sf.data(), 8, &kf) != ORBFE_OK) return 8;
+        std::vector<uint8_t> has((size_t)n, 1);
+        std::vector<orbfe_keypoint> kp2((size_t)cap);
+        std::vector<uint8_t> desc2((size_t)cap * 32);
+        int n2 = 0, nmR = 0;
+        const double tr = median_us([&] {
+            rc |= orbfe_track_reference_keyframe(h, img.data(), W, voc, levelsup, kf, has.data(), 0.75f, 1, kp2.data(), desc2.data(), &n2, nullptr,
+                                                 word.data(), node.data(), w.data(), matchR.data(), &nmR);
+        }, reps);
+        int self = 0;
+        for (int i = 0; i < n2; i++) self += matchR[(size_t)i] == i;
+        std::printf("c_abi_latency_us track_reference_keyframe=%.1f keypoints=%d ref_matches=%d self=%d rc=%d\n", tr, n2, nmR, self, rc);
+        orbfe_keyframe_destroy(kf);
+        orbfe_vocab_destroy(voc);
+    }
     orbfe_map_destroy(map);
     orbfe_destroy(h);
     return rc == 0 && same ? 0 : 6;

@@ -46,7 +46,16 @@ def test_track_latency_program_runs_and_agrees_with_the_oracle(built, tmp_path):
     (tmp_path / "g.raw").write_bytes(img.tobytes())
     (tmp_path / "w.bin").write_bytes(rec.tobytes())
     (tmp_path / "f.bin").write_bytes(bytes(Fp))
-    out = subprocess.check_output([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "w.bin"), str(M), str(tmp_path / "f.bin"), "100"]).decode()
+    # a vocabulary (k = 10, L = 4, levelsup 2: ~100 nodes at the FeatureVector level) as a binary dump for the fourth timing
+    import vocab_synth as vs
+    t = vs.spread_first_level(vs.make_tree(10, 4, seed=3, early_leaf_p=0.03), 4)
+    levelsup = 2
+    with open(tmp_path / "voc.bin", "wb") as fvoc:
+        fvoc.write(np.array([len(t["wordId"]), len(t["childIdx"]), 4, levelsup], np.int32).tobytes())
+        for a, dt in ((t["childOff"], np.int32), (t["childIdx"], np.int32), (t["wordId"], np.int32), (t["nodeDesc"], np.uint8), (t["weight"], np.float64)):
+            fvoc.write(np.ascontiguousarray(a, dt).tobytes())
+    out = subprocess.check_output([BIN, str(W), str(H), str(tmp_path / "g.raw"), str(tmp_path / "w.bin"), str(M), str(tmp_path / "f.bin"), "100",
+                                   str(tmp_path / "voc.bin")]).decode()
     m = re.search(r"c_abi_latency_us extract=([0-9.]+) track_frame=([0-9.]+) track_frame_map=([0-9.]+) keypoints=(\d+) matches=(\d+) same=1 rc=0", out)
     assert m, out
     mps, _ = O.is_in_frustum(Fo, pts)
@@ -55,3 +64,15 @@ def test_track_latency_program_runs_and_agrees_with_the_oracle(built, tmp_path):
     assert int(m.group(4)) == len(kp) and int(m.group(5)) == n_ref and n_ref > 500
     assert float(m.group(1)) < float(m.group(2)) < 5000.0
     print(m.group(0))
+    # the chain against the reference key frame from C++: the frame's own features as the key frame, checked against the oracle
+    mr = re.search(r"c_abi_latency_us track_reference_keyframe=([0-9.]+) keypoints=(\d+) ref_matches=(\d+) self=(\d+) rc=0", out)
+    assert mr, out
+    _, node, _ = O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 4, desc, levelsup)
+    kfOff, kfIdx = [0], []
+    for g in sorted(set(node.tolist())):
+        kfIdx += list(np.flatnonzero(node == g))
+        kfOff.append(len(kfIdx))
+    n_b, m_b = O.search_by_bow(kfOff, kfIdx, kfOff, kfIdx, desc, kp["angle"], np.ones(len(kp), np.uint8), desc, kp["angle"], 0.75, True)
+    assert int(mr.group(2)) == len(kp) and int(mr.group(3)) == n_b and int(mr.group(4)) == int((m_b == np.arange(len(kp))).sum()) and n_b > 500
+    assert float(mr.group(1)) < float(m.group(2))  # cheaper than the projection chain at 2000 map points
+    print(mr.group(0))
