@@ -652,6 +652,17 @@ int orbfe_track_reference_keyframe(orbfe_handle *h, const uint8_t *gray, int pit
  * Misc
  * ---------------------------------------------------------------------------------------- */
 const char *orbfe_status_string(int status);
+/* The host-pointer entry points capture their launch sequence into a hipGraph the first time a shape is seen (on a throw-away
+ * stream) and replay it afterwards.  On ROCm 7.2 a NULL-stream operation of ANOTHER thread of the process (a plain hipMemcpy /
+ * hipMemset of the application) that meets a capture in flight is refused by the runtime with hipErrorStreamCaptureImplicit
+ * and kills the capture: the library call then runs on plain launches and is unaffected, but the application's call has
+ * failed.  An application that uses the NULL stream from other threads can switch capturing off (enable = 0: plain launches,
+ * about 0.04 ms more per single-frame call) or make its first call of every shape before those threads start.  The
+ * library itself never uses the NULL stream. */
+int orbfe_set_graph_capture(orbfe_handle *h, int enable);
+/* diagnostics: graphs this handle has captured so far, and captures that failed (e.g. invalidated by another thread's NULL-stream
+ * call: the affected call ran on plain launches, its result is unaffected; after 8 failures a handle stops capturing) */
+int orbfe_debug_graph_stats(orbfe_handle *h, int *captured, int *failed);
 /* message of the last failing HIP call on this handle ("" if none) */
 const char *orbfe_last_error(const orbfe_handle *h);
 /* library / build identification, e.g. "orbfe 0.1 gfx950" */

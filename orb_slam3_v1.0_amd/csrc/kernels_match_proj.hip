@@ -1184,7 +1184,7 @@ int match_projection_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view*
 #ifdef ORBFE_DIAG
     if (getenv("ORBFE_DEBUG_MATCH")) {  // liborbfe_diag.so only (tools/diag_match.py, tools/resolve_stats.py)
         int dbg[4] = {0, 0, 0, 0};
-        (void)hipMemcpy(dbg, A.dbg, sizeof dbg, hipMemcpyDeviceToHost);
+        (void)copy_sync(dbg, A.dbg, sizeof dbg, hipMemcpyDeviceToHost, s);
         fprintf(stderr, "[orbfe] match_projection: n=%d M=%d sweeps=%d cooperative_rescans=%d\n", n, M, dbg[0], dbg[1]);
     }
 #endif

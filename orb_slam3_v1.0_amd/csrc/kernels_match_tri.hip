@@ -532,7 +532,7 @@ int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* of
 // resident key frames (keyframe.h)
 // ---------------------------------------------------------------------------------------------
 int keyframe_create(int n, const orbfe_keypoint* kp, const uint8_t* desc, const int* nodeId, const uint8_t* stereo,
-                    const float* sf, int nLevels, KeyFrameDev** out, std::string& err)
+                    const float* sf, int nLevels, hipStream_t s, KeyFrameDev** out, std::string& err)
 {
     *out = nullptr;
     if (n < 0 || nLevels < 1 || nLevels > kMaxLevels || (n > 0 && (!kp || !desc || !nodeId)) || !sf) return ORBFE_ERR_INVALID_ARG;
@@ -580,7 +580,7 @@ int keyframe_create(int n, const orbfe_keypoint* kp, const uint8_t* desc, const 
         err = "hipMalloc(key frame) failed";
         return ORBFE_ERR_OUT_OF_MEMORY;
     }
-    if (hipMemcpy(K->block, img.data(), c.off, hipMemcpyHostToDevice) != hipSuccess) {
+    if (copy_sync(K->block, img.data(), c.off, hipMemcpyHostToDevice, s) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(K->block);
         delete K;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void vocab_transform_kernel(const int* __restr
 }  // namespace
 
 int vocab_create(int nNodes, const int* childOff, const int* childIdx, const uint8_t* nodeDesc, const int* wordId,
-                 const double* weight, int L, Vocab** out, std::string& err)
+                 const double* weight, int L, hipStream_t s, Vocab** out, std::string& err)
 {
     *out = nullptr;
     if (nNodes < 2 || childOff[0] != 0 || childOff[1] == 0) return ORBFE_ERR_INVALID_ARG;  // root must have children
@@ -100,11 +100,11 @@ int vocab_create(int nNodes, const int* childOff, const int* childIdx, const uin
     VC(hipMalloc(&v->dDesc, (size_t)nNodes * 32));
     VC(hipMalloc(&v->dWordId, (size_t)nNodes * sizeof(int)));
     VC(hipMalloc(&v->dWeight, (size_t)nNodes * sizeof(double)));
-    VC(hipMemcpy(v->dChildOff, childOff, (size_t)(nNodes + 1) * sizeof(int), hipMemcpyHostToDevice));
-    VC(hipMemcpy(v->dChildIdx, childIdx, (size_t)nEdges * sizeof(int), hipMemcpyHostToDevice));
-    VC(hipMemcpy(v->dDesc, nodeDesc, (size_t)nNodes * 32, hipMemcpyHostToDevice));
-    VC(hipMemcpy(v->dWordId, wordId, (size_t)nNodes * sizeof(int), hipMemcpyHostToDevice));
-    VC(hipMemcpy(v->dWeight, weight, (size_t)nNodes * sizeof(double), hipMemcpyHostToDevice));
+    VC(copy_sync(v->dChildOff, childOff, (size_t)(nNodes + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    VC(copy_sync(v->dChildIdx, childIdx, (size_t)nEdges * sizeof(int), hipMemcpyHostToDevice, s));
+    VC(copy_sync(v->dDesc, nodeDesc, (size_t)nNodes * 32, hipMemcpyHostToDevice, s));
+    VC(copy_sync(v->dWordId, wordId, (size_t)nNodes * sizeof(int), hipMemcpyHostToDevice, s));
+    VC(copy_sync(v->dWeight, weight, (size_t)nNodes * sizeof(double), hipMemcpyHostToDevice, s));
 #undef VC
     *out = v;
     return ORBFE_OK;

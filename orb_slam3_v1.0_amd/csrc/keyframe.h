@@ -28,7 +28,7 @@ struct KeyFrameDev {
 };
 
 int keyframe_create(int n, const orbfe_keypoint* kp, const uint8_t* desc, const int* nodeId, const uint8_t* stereo,
-                    const float* sf, int nLevels, KeyFrameDev** out, std::string& err);
+                    const float* sf, int nLevels, hipStream_t s, KeyFrameDev** out, std::string& err);
 void keyframe_destroy(KeyFrameDev* K);
 
 // SearchForTriangulation of key frame 1 against K neighbours in one launch: raw matches + rotation bins per (neighbour,

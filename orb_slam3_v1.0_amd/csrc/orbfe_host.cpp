@@ -87,6 +87,7 @@ struct orbfe_handle {
     // the whole host-API call (H2D, kernel chain, D2H) as a captured hipGraph per batch size (latency path)
     std::map<int, hipGraphExec_t> graphs;
     bool useGraph = true;
+    int graphCaptures = 0, captureFailures = 0;  // orbfe_debug_graph_stats
 
     hipStream_t stream = nullptr;
     bool timing = false;
@@ -426,12 +427,12 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
             for (int ty = 0; ty < P.lv[l].tilesY; ty++)
                 for (int tx = 0; tx < P.lv[l].tilesX; tx++) info[P.lv[l].tileBase + ty * P.lv[l].tilesX + tx] = fast_tile_info(l, tx, ty);
         CREATE_CHK(hipMalloc(&h->dTileInfo, info.size() * sizeof(uint32_t)));
-        CREATE_CHK(hipMemcpy(h->dTileInfo, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        CREATE_CHK(copy_sync(h->dTileInfo, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     }
     CREATE_CHK(hipMalloc(&h->dSf, kMaxLevels * sizeof(float)));
-    CREATE_CHK(hipMemcpy(h->dSf, h->sf, kMaxLevels * sizeof(float), hipMemcpyHostToDevice));
-    CREATE_CHK(hipMemcpy(h->dP, &P, sizeof P, hipMemcpyHostToDevice));
-    CREATE_CHK(hipMemcpy(h->dTabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CREATE_CHK(copy_sync(h->dSf, h->sf, kMaxLevels * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    CREATE_CHK(copy_sync(h->dP, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    CREATE_CHK(copy_sync(h->dTabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 
     // staging for the host-pointer entry points
     h->dInPitch = (int)align_up((size_t)p->image_width, kPitchAlign);
@@ -651,6 +652,61 @@ static int extract_host_enqueue(orbfe_handle* h, int batch, int inPitch, hipStre
     return ORBFE_OK;
 }
 
+// Graphs are captured on a THROW-AWAY stream, never on the handle's (or a caller's) own.  On this runtime (ROCm 7.2) a
+// NULL-stream operation of any other thread of the process -- a plain hipMemcpy of the application -- that meets a capture in
+// flight fails with hipErrorStreamCaptureImplicit AND leaves the capturing stream unusable for good, whatever the capture mode
+// and although the stream is non-blocking (tools/probes/capture_invalidate.cpp): every later call on it returns
+// hipErrorStreamCaptureInvalidated.  With a throw-away stream such an encounter costs the call that was capturing its graph,
+// not the handle: the stream is destroyed, the call runs on plain launches, a later call captures again.  Only a handle
+// whose captures keep failing stops trying.  (The library itself makes no NULL-stream call: copy_sync / memset_sync.)
+struct CaptureStream {
+    hipStream_t s = nullptr;
+    bool capturing = false;
+    bool begin()
+    {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            s = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        capturing = true;
+        return true;
+    }
+    // the captured graph, or null if the capture did not survive
+    hipGraph_t end()
+    {
+        hipGraph_t g = nullptr;
+        if (capturing) {
+            capturing = false;
+            if (hipStreamEndCapture(s, &g) != hipSuccess) {
+                (void)hipGetLastError();
+                if (g) (void)hipGraphDestroy(g);
+                g = nullptr;
+            }
+        }
+        return g;
+    }
+    ~CaptureStream()
+    {
+        if (capturing) {
+            hipGraph_t g = end();
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (s) (void)hipStreamDestroy(s);
+        (void)hipGetLastError();
+    }
+};
+
+static void graph_capture_failed(orbfe_handle* h)
+{
+    (void)hipGetLastError();
+    if (++h->captureFailures >= 8) h->useGraph = false;
+}
+
 // extract_host_enqueue, replayed from a hipGraph when possible: every pointer behind the upload is owned by the
 // handle, so the enqueue sequence (memset, 10 kernels, result copy) is captured once per (batch, input pitch) and
 // replayed with a single hipGraphLaunch
@@ -666,25 +722,29 @@ static int extract_enqueue_replay(orbfe_handle* h, int batch, int inPitch, hipSt
         hipGraphExec_t& exec = h->graphs[gkey];
         if (!exec) {
             hipGraph_t graph = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = extract_host_enqueue(h, batch, inPitch, s);
-            const hipError_t ec = hipStreamEndCapture(s, &graph);
-            if (rc != ORBFE_OK || ec != hipSuccess || !graph) {
+            {
+                CaptureStream cs;
+                rc = cs.begin() ? extract_host_enqueue(h, batch, inPitch, cs.s) : ORBFE_ERR_HIP;
+                graph = cs.end();
+            }
+            if (rc != ORBFE_OK || !graph) {
+                rc = ORBFE_OK;
                 if (graph) (void)hipGraphDestroy(graph);
                 h->graphs.erase(gkey);
-                h->useGraph = false;  // fall back to plain launches for the lifetime of the handle
-                (void)hipGetLastError();
+                graph_capture_failed(h);
+                viaGraph = false;  // plain launches below
             } else {
                 const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
                 if (ei != hipSuccess) {
                     h->graphs.erase(gkey);
-                    h->useGraph = false;
-                    (void)hipGetLastError();
+                    graph_capture_failed(h);
+                    viaGraph = false;
+                } else {
+                    h->graphCaptures++;
                 }
             }
         }
-        viaGraph = h->useGraph;  // capture may have failed: plain launches below
         if (viaGraph) {
             {
                 const int rca = scratch_acquire(h, h->extractUsed, h->extractStream, h->evExtract, s);
@@ -986,17 +1046,18 @@ static int track_frame_impl(orbfe_handle* h, const uint8_t* gray, int pitch, con
             if (memcmp(&g.key, &key, sizeof key) == 0) exec = g.exec;
         if (!exec) {
             hipGraph_t graph = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = track_enqueue(h, L, Mb, inPitch, A, map, s);
-            const hipError_t ec = hipStreamEndCapture(s, &graph);
-            if (rc == ORBFE_OK && ec == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
-                exec = nullptr;
+            {
+                CaptureStream cs;
+                rc = cs.begin() ? track_enqueue(h, L, Mb, inPitch, A, map, cs.s) : ORBFE_ERR_HIP;
+                graph = cs.end();
+            }
+            if (rc == ORBFE_OK && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
             if (graph) (void)hipGraphDestroy(graph);
             if (!exec) {
-                (void)hipGetLastError();
-                h->useGraph = false;  // plain launches for the lifetime of the handle
+                graph_capture_failed(h);  // plain launches for this call
                 viaGraph = false;
             } else {
+                h->graphCaptures++;
                 if (h->trackGraphs.size() >= 64) track_drop_graphs(h);  // a caller cycling through parameters: bounded cache
                 h->trackGraphs.push_back({key, exec});
             }
@@ -1559,15 +1620,15 @@ int orbfe_map_create(orbfe_handle* h, int capacity, orbfe_map** out)
     std::vector<orbfe_world_point> init((size_t)std::min(capacity, 1 << 16));
     for (auto& p : init) { p = orbfe_world_point{}; p.bad = 1; }
     for (size_t o = 0; o < (size_t)capacity; o += init.size())
-        if (hipMemcpy(m->dPts + o, init.data(), std::min(init.size(), (size_t)capacity - o) * sizeof(orbfe_world_point),
-                      hipMemcpyHostToDevice) != hipSuccess) {
+        if (copy_sync(m->dPts + o, init.data(), std::min(init.size(), (size_t)capacity - o) * sizeof(orbfe_world_point),
+                      hipMemcpyHostToDevice, h->stream) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(m->dPts);
             (void)hipFree(m->dDesc);
             delete m;
             return ORBFE_ERR_HIP;
         }
-    (void)hipMemset(m->dDesc, 0, (size_t)capacity * ORBFE_DESC_BYTES);
+    (void)memset_sync(m->dDesc, 0, (size_t)capacity * ORBFE_DESC_BYTES, h->stream);
     *out = m;
     return ORBFE_OK;
 }
@@ -1660,7 +1721,7 @@ int orbfe_debug_get_candidates(orbfe_handle* h, int frame, int level, uint32_t* 
     HIPCHK(h, hipSetDevice(h->device));
     if (h->extractUsed) HIPCHK(h, hipEventSynchronize(h->evExtract));
     uint32_t c[kCntWords];
-    HIPCHK(h, hipMemcpy(c, h->dCounters + ((size_t)frame * h->nLevels + level) * kCntWords, sizeof c, hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(c, h->dCounters + ((size_t)frame * h->nLevels + level) * kCntWords, sizeof c, hipMemcpyDeviceToHost, h->stream));
     const LevelDesc& L = h->P.lv[level];
     int n = (int)std::min<uint32_t>(c[kCntCand], (uint32_t)L.candCap);
     if (counters) {
@@ -1671,9 +1732,27 @@ int orbfe_debug_get_candidates(orbfe_handle* h, int frame, int level, uint32_t* 
     }
     const int m = std::min(n, cap);
     if (packed && m > 0)
-        HIPCHK(h, hipMemcpy(packed, h->dCand + L.candOff + (size_t)frame * L.candCap, (size_t)m * sizeof(uint32_t),
-                            hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(packed, h->dCand + L.candOff + (size_t)frame * L.candCap, (size_t)m * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, h->stream));
     *n_out = m;
+    return ORBFE_OK;
+}
+
+int orbfe_set_graph_capture(orbfe_handle* h, int enable)
+{
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->useGraph = enable != 0;
+    if (enable) h->captureFailures = 0;
+    return ORBFE_OK;
+}
+
+int orbfe_debug_graph_stats(orbfe_handle* h, int* captured, int* failed)
+{
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (captured) *captured = h->graphCaptures;
+    if (failed) *failed = h->captureFailures;
     return ORBFE_OK;
 }
 
@@ -1686,7 +1765,7 @@ int orbfe_get_device_status(orbfe_handle* h, unsigned* flags_out)
     if (h->extractUsed && h->lastBatch > 0) {
         HIPCHK(h, hipEventSynchronize(h->evExtract));
         std::vector<uint32_t> c((size_t)h->lastBatch * h->nLevels * kCntWords);
-        HIPCHK(h, hipMemcpy(c.data(), h->dCounters, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(c.data(), h->dCounters, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         for (size_t i = 0; i < (size_t)h->lastBatch * h->nLevels; i++) flags |= c[i * kCntWords + kCntStatus];
     }
     if (flags_out) *flags_out = flags;
@@ -1972,7 +2051,7 @@ int orbfe_keyframe_create(orbfe_handle* h, int n, const orbfe_keypoint* kp, cons
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
     orbfe::KeyFrameDev* k = nullptr;
-    const int rc = keyframe_create(n, kp, desc, node_id, stereo, scale_factors, n_levels, &k, err);
+    const int rc = keyframe_create(n, kp, desc, node_id, stereo, scale_factors, n_levels, h->stream, &k, err);
     if (rc != ORBFE_OK) {
         h->err = err;
         return rc;
@@ -2119,8 +2198,8 @@ int orbfe_prep_create(orbfe_handle* h, int src_w, int src_h, const float* map1, 
               hipHostMalloc(&p->hSrc, (size_t)p->srcPitch * src_h) == hipSuccess &&
               hipMalloc(&p->dGray, (size_t)p->grayPitch * dst_h) == hipSuccess &&
               hipHostMalloc(&p->hGray, (size_t)p->grayPitch * dst_h) == hipSuccess;
-    ok = ok && hipMemcpy(p->dMap1, map1, mapBytes, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(p->dMap2, map2, mapBytes, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && copy_sync(p->dMap1, map1, mapBytes, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+         copy_sync(p->dMap2, map2, mapBytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         orbfe_prep_destroy(p);
@@ -2240,7 +2319,7 @@ int orbfe_vocab_create(orbfe_handle* h, int n_nodes, const int* child_off, const
     HIPCHK(h, hipSetDevice(h->device));
     std::string err;
     orbfe::Vocab* v = nullptr;
-    const int rc = vocab_create(n_nodes, child_off, child_idx, node_desc, word_id, weight, L, &v, err);
+    const int rc = vocab_create(n_nodes, child_off, child_idx, node_desc, word_id, weight, L, h->stream, &v, err);
     if (rc != ORBFE_OK) {
         h->err = err;
         return rc;
@@ -2463,17 +2542,18 @@ extern "C" int orbfe_track_reference_keyframe(orbfe_handle* h, const uint8_t* gr
             if (memcmp(&g.key, &key, sizeof key) == 0) exec = g.exec;
         if (!exec) {
             hipGraph_t graph = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = ref_enqueue(h, L, inPitch, vocab->v, levelsup, nn_ratio, check_orientation, s);
-            const hipError_t ec = hipStreamEndCapture(s, &graph);
-            if (rc == ORBFE_OK && ec == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
-                exec = nullptr;
+            {
+                CaptureStream cs;
+                rc = cs.begin() ? ref_enqueue(h, L, inPitch, vocab->v, levelsup, nn_ratio, check_orientation, cs.s) : ORBFE_ERR_HIP;
+                graph = cs.end();
+            }
+            if (rc == ORBFE_OK && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
             if (graph) (void)hipGraphDestroy(graph);
             if (!exec) {
-                (void)hipGetLastError();
-                h->useGraph = false;  // plain launches for the lifetime of the handle
+                graph_capture_failed(h);  // plain launches for this call
                 viaGraph = false;
             } else {
+                h->graphCaptures++;
                 if (h->refGraphs.size() >= 16) ref_drop_graphs(h);  // vocabularies / parameters cycling: bounded cache
                 h->refGraphs.push_back({key, exec});
             }

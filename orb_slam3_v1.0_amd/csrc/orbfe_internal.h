@@ -6,6 +6,24 @@
 
 #include "../../include/orbfe.h"
 
+// Synchronous copies / fills that stay OFF the NULL stream.  A null-stream operation (hipMemcpy, hipMemset) waits for every
+// other stream of the device; if another thread is capturing one of them into a graph (a per-frame chain on another handle,
+// or the application's own graphs), HIP fails the copy AND invalidates that capture -- seen with the tracking thread capturing
+// orbfe_track_frame while the mapping thread uploaded a key frame (tests/test_two_threads_gpu.py).  These run on the
+// caller's own (non-blocking) stream and wait for it alone.
+inline hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+inline hipError_t memset_sync(void* dst, int value, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+
 namespace orbfe {
 
 constexpr int kMaxLevels = ORBFE_MAX_LEVELS;

@@ -23,7 +23,7 @@ struct Vocab {
 };
 
 int vocab_create(int nNodes, const int* childOff, const int* childIdx, const uint8_t* nodeDesc, const int* wordId,
-                 const double* weight, int L, Vocab** out, std::string& err);
+                 const double* weight, int L, hipStream_t s, Vocab** out, std::string& err);
 void vocab_destroy(Vocab* v);
 int vocab_transform(Vocab* v, hipStream_t s, const uint8_t* desc, int n, int levelsup, int* wordOut, int* nodeOut,
                     double* weightOut, std::string& err);

@@ -118,7 +118,7 @@ SYMBOLS = [
     "orbfe_stream_collect_view", "orbfe_stream_in_flight", "orbfe_track_frame",
     "orbfe_keyframe_create", "orbfe_keyframe_destroy", "orbfe_keyframe_size", "orbfe_match_triangulation_batch",
     "orbfe_triangulation_select", "orbfe_map_create", "orbfe_map_destroy", "orbfe_map_update", "orbfe_stream_enable_track",
-    "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map", "orbfe_track_reference_keyframe",
+    "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map", "orbfe_track_reference_keyframe", "orbfe_debug_graph_stats", "orbfe_set_graph_capture",
 ]
 
 _lib = None
@@ -164,6 +164,8 @@ def lib():
     L.orbfe_extract.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.orbfe_extract_batch.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.orbfe_get_device_status.argtypes = [vp, vp]
+    L.orbfe_debug_graph_stats.argtypes = [vp, vp, vp]
+    L.orbfe_set_graph_capture.argtypes = [vp, ci]
     L.orbfe_stream_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
     L.orbfe_stream_destroy.argtypes = [vp]
     L.orbfe_stream_destroy.restype = None
@@ -354,6 +356,15 @@ class ORBextractor:
         self._chk(self.L.orbfe_debug_get_candidates(self.h, frame, level, _p(packed), cap, C.byref(n), _p(cnt)),
                   "debug_candidates")
         return packed[:n.value].copy(), cnt
+
+    def set_graph_capture(self, on):
+        self._chk(self.L.orbfe_set_graph_capture(self.h, int(bool(on))), "orbfe_set_graph_capture")
+
+    def graph_stats(self):
+        """(graphs captured, captures that failed and fell back to plain launches) of this handle"""
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.L.orbfe_debug_graph_stats(self.h, C.byref(a), C.byref(b)), "orbfe_debug_graph_stats")
+        return a.value, b.value
 
     def set_stage_timing(self, on):
         self._chk(self.L.orbfe_set_stage_timing(self.h, int(on)), "set_stage_timing")
