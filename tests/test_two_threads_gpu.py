@@ -116,6 +116,30 @@ def test_tracking_and_mapping_threads_run_concurrently(built, shared_handle):
     assert any(w[0] == "track" and w[4] > 300 for w in want_t) and any(w[0] == "ref" and w[4] > 100 for w in want_t)
 
 
+def test_two_tracking_threads_capture_their_graphs_at_the_same_time(built):
+    """Two cameras, two tracking threads, two handles: both capture their graphs (thread-local capture mode, throw-away
+    streams) and replay them at the same time."""
+    import orbfe
+    from orbfe import synth
+    frames = list(synth.stream(W, H, 6, index0=970))
+    exs = [orbfe.ORBextractor(*ARGS, device=0, max_batch=1) for _ in range(2)]
+    n_iter = 30
+    work = [_tracking_work(orbfe, ex, frames[i:] + frames[:i], n_iter) for i, ex in enumerate(exs)]
+    outs, errs = [[], []], []
+    ths = [threading.Thread(target=_run, args=(work[i][0], outs[i], errs)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=240)
+        assert not t.is_alive(), "a thread did not finish"
+    assert not errs, errs
+    for i in range(2):
+        want = [c() for c in work[i][0]]
+        assert outs[i] == want, "tracking thread %d changed under concurrency" % i
+        captured, failed = exs[i].graph_stats()
+        assert failed == 0 and captured >= 5  # extract, three map-point buckets, the reference-key-frame chain
+
+
 def test_foreign_null_stream_traffic_does_not_break_a_call(built):
     """The application's own GPU code runs next to the library: here another thread hammers the NULL stream (synchronous
     hipMemcpy) while this one makes calls that each capture a NEW graph (a new map-point
