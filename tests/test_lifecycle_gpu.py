@@ -1,0 +1,131 @@
+"""A SLAM process runs for hours: key frames come and go by the thousand, maps and rings are rebuilt on relocalisation, a
+handle may be re-created when the camera configuration changes.  Create / use / destroy cycles of every object the library
+hands out must give back what they took: device memory (hipMemGetInfo) and host memory (pinned staging shows up in the
+process's resident set) after many cycles stay where they were after the first few."""
+import gc
+import os
+
+import numpy as np
+import pytest
+
+import frustum_scenarios as FS
+import oracle_py as O
+import vocab_synth as vs
+from test_frustum import PN
+
+pytestmark = pytest.mark.gpu
+
+ARGS = (1000, 40000, 1.2, 8, 20, 7, 752, 480)
+W, H = ARGS[6], ARGS[7]
+
+
+def _rss_mb():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2 ** 20
+
+
+def _free_mb():
+    import torch
+    return torch.cuda.mem_get_info(0)[0] / 2 ** 20
+
+
+def test_objects_give_back_what_they_took(built):
+    import orbfe
+    from orbfe import synth
+    frames = list(synth.stream(W, H, 3, index0=40))
+    t = vs.spread_first_level(vs.make_tree(8, 4, seed=2), 3)
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=4)
+    kp0, desc0 = ex.extractFeatures(frames[0])
+    Fp = orbfe.Frustum()
+    v = FS.fill_frustum(Fp, PN, W=float(W), H=float(H), seed=21)
+    pts, mpd = FS.world_points_on_keypoints(kp0.view(O.KP_DTYPE), desc0, v, 2500, np.random.default_rng(1), 8)
+    pts = pts.view(orbfe.WP_DTYPE)
+    node = (np.arange(len(kp0)) % 97).astype(np.int32)
+
+    def small_objects():
+        """what comes and goes while ONE handle lives"""
+        for _ in range(20):
+            kf = orbfe.KeyFrame(ex, kp0, desc0, node, ex.mvScaleFactor)
+            kf.close()
+        voc = orbfe.ORBVocabulary(ex, t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 4)
+        voc.transform(desc0, 2)
+        voc.close()
+        mp = orbfe.MapPoints(ex, 3000)
+        mp.update(np.arange(100), pts[:100], mpd[:100])
+        st = ex.stream(slots=3, slot_frames=4)
+        st.enable_track(mp, 200, 64, 48, 0.0, 0.0, float(W), float(H))
+        st.submit(np.stack(frames[:3]))
+        st.collect()
+        st.close()
+        mp.close()
+
+    def whole_handle():
+        """a handle's life: every entry point that captures graphs or grows an arena, then destroy"""
+        e2 = orbfe.ORBextractor(*ARGS, device=0, max_batch=2)
+        trk = orbfe.FrameTracker(e2, 64, 48, 0.0, 0.0, float(W), float(H))
+        m = orbfe.ORBmatcher(e2)
+        e2.extract_batch(frames[:2])
+        for M in (300, 1200, 2500):
+            trk.TrackFrame(frames[1], Fp, pts[:M], mpd[:M], 20.0, 0.85)
+        voc = orbfe.ORBVocabulary(e2, t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 4)
+        k, d = e2.extractFeatures(frames[2])
+        _, nd, _ = voc.transform(d, 2)
+        kf = orbfe.KeyFrame(e2, k, d, nd, e2.mvScaleFactor)
+        trk.TrackReferenceKeyFrame(frames[0], voc, 2, kf, np.ones(len(k), np.uint8))
+        mps, _ = m.isInFrustum_batch(Fp, pts)
+        fv = orbfe.make_frame_view(k, d, 64, 48, 0.0, 0.0, float(W), float(H), e2.mvScaleFactor)
+        m.SearchByProjection(fv, mps, mpd, 20.0, False, 0.0, 0.85, None)
+        kf.close()
+        voc.close()
+        e2.close()
+
+    for _ in range(3):  # warm-up: allocator pools, code objects, lazily created runtime state
+        small_objects()
+        whole_handle()
+    gc.collect()
+    free0, rss0 = _free_mb(), _rss_mb()
+    for _ in range(25):
+        small_objects()
+    for _ in range(12):
+        whole_handle()
+    gc.collect()
+    free1, rss1 = _free_mb(), _rss_mb()
+    print("device free %.0f -> %.0f MB, host RSS %.0f -> %.0f MB over 500 key frames, 25 vocabularies / maps / rings, 12 handles" % (
+        free0, free1, rss0, rss1))
+    assert free0 - free1 < 32, "device memory shrank by %.0f MB" % (free0 - free1)
+    assert rss1 - rss0 < 96, "host memory grew by %.0f MB" % (rss1 - rss0)
+
+
+def test_graph_cache_is_bounded_and_survives_its_own_eviction(built):
+    """A caller that cycles through more parameter sets than the per-handle graph cache holds (64 for orbfe_track_frame):
+    the cache is dropped and refilled, every call still returns what the three separate calls return, and the device
+    memory the dropped graphs held comes back."""
+    import orbfe
+    from orbfe import synth
+    img = synth.frame(W, H, 77)
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=1)
+    trk = orbfe.FrameTracker(ex, 64, 48, 0.0, 0.0, float(W), float(H))
+    m = orbfe.ORBmatcher(ex)
+    kp0, desc0 = ex.extractFeatures(img)
+    Fp = orbfe.Frustum()
+    v = FS.fill_frustum(Fp, PN, W=float(W), H=float(H), seed=5)
+    pts, mpd = FS.world_points_on_keypoints(kp0.view(O.KP_DTYPE), desc0, v, 1200, np.random.default_rng(2), 8)
+    pts = pts.view(orbfe.WP_DTYPE)
+    mps, _ = m.isInFrustum_batch(Fp, pts)
+    fv = orbfe.make_frame_view(kp0, desc0, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+    for i in range(3):
+        trk.TrackFrame(img, Fp, pts, mpd, 5.0 + i, 0.85)
+    free0 = _free_mb()
+    c0 = ex.graph_stats()[0]
+    for i in range(150):  # 150 distinct radii: 150 graph keys through a 64-entry cache
+        th = 8.0 + 0.25 * i
+        got = trk.TrackFrame(img, Fp, pts, mpd, th, 0.85)
+        if i % 10 == 0:
+            n3, match3 = m.SearchByProjection(fv, mps, mpd, th, False, 0.0, 0.85, None)
+            assert got["nmatches"] == n3 and np.array_equal(got["match"], match3), "th %.2f" % th
+    captured, failed = ex.graph_stats()
+    assert captured - c0 == 150 and failed == 0
+    again = trk.TrackFrame(img, Fp, pts, mpd, 8.0, 0.85)  # evicted long ago: captured once more
+    n3, match3 = m.SearchByProjection(fv, mps, mpd, 8.0, False, 0.0, 0.85, None)
+    assert again["nmatches"] == n3 and np.array_equal(again["match"], match3)
+    assert free0 - _free_mb() < 32
