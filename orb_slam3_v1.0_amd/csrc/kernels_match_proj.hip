@@ -270,11 +270,15 @@ __device__ __forceinline__ void proj_sort_body(const ProjArgs& A)
 template <bool LDS, bool SORT_MPS>
 __global__ __launch_bounds__(1024) void proj_prepare_kernel(ProjArgs A)
 {
-    proj_grid_body<LDS>(A);
+    // the two sides are independent: with SORT_MPS the launch has two blocks per frame (blockIdx.y), one per side -- a single
+    // frame's call then pays the longer of the two instead of their sum
     if constexpr (SORT_MPS) {
-        __syncthreads();
-        proj_sort_body(A);
+        if (blockIdx.y == 1) {
+            proj_sort_body(A);
+            return;
+        }
     }
+    proj_grid_body<LDS>(A);
 }
 
 // Thread per map point: walk the storage range of every (level, grid column) of the window (cells
@@ -993,8 +997,8 @@ void proj_prepare_launch(hipStream_t s, const ProjArgs& A, bool sortMps)
 {
     const bool lds = A.kpStride <= kSortLds;
     if (sortMps) {
-        if (lds) hipLaunchKernelGGL((proj_prepare_kernel<true, true>), dim3(A.B), dim3(1024), 0, s, A);
-        else hipLaunchKernelGGL((proj_prepare_kernel<false, true>), dim3(A.B), dim3(1024), 0, s, A);
+        if (lds) hipLaunchKernelGGL((proj_prepare_kernel<true, true>), dim3(A.B, 2), dim3(1024), 0, s, A);
+        else hipLaunchKernelGGL((proj_prepare_kernel<false, true>), dim3(A.B, 2), dim3(1024), 0, s, A);
     } else {
         if (lds) hipLaunchKernelGGL((proj_prepare_kernel<true, false>), dim3(A.B), dim3(1024), 0, s, A);
         else hipLaunchKernelGGL((proj_prepare_kernel<false, false>), dim3(A.B), dim3(1024), 0, s, A);
