@@ -26,7 +26,8 @@
 
 namespace orbfe {
 
-constexpr int kQtThreads = 512;
+constexpr int kQtThreads = 512;   // block size of the throughput launches (many frames: four blocks share a CU)
+constexpr int kQtThreadsSmall = 1024;  // a single frame's call: half as many trips through every candidate loop
 constexpr int kQtMaxRounds = 48;
 constexpr uint32_t kKeyInf = 0x01000000u;  // larger than any raster key
 
@@ -56,6 +57,7 @@ __device__ __forceinline__ Box child_box(const Box& b, int c)
 }
 
 // exclusive scan of one int per thread across the block (tid order); all threads must call.
+template <int NT>
 __device__ __forceinline__ int block_excl_scan(int v, int& total, int* sWave)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,7 +76,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int& total, int* sWave)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < kQtThreads / 64; i++) {
+    for (int i = 0; i < NT / 64; i++) {
         const int s = sWave[i];
         if (i < wave) base += s;
         tot += s;
@@ -87,6 +89,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int& total, int* sWave)
 // of this level, plus one.  The cutoff row comes from the per-tile-row counts the FAST kernel
 // stored; the cutoff column from re-running the segment test along that single row.  Block-wide,
 // every thread returns the same value.  Only called when the level has more than nFast corners.
+template <int NT>
 __device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const LevelDesc& L, int f, int l, bool high,
                                     int nFast, const uint8_t* __restrict__ gray0, size_t gray0FrameStride, int gray0Pitch,
                                     const uint8_t* __restrict__ ws, const uint32_t* __restrict__ tileRows, int* sWave,
@@ -97,7 +100,7 @@ __device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const Le
     if (tid == 0) { sRed[0] = -1; sRed[1] = 0; sRed[2] = -1; }
     __syncthreads();
     int carry = 0;
-    for (int base = 0; base < L.h; base += kQtThreads) {  // row where the running corner count reaches nFast
+    for (int base = 0; base < L.h; base += NT) {  // row where the running corner count reaches nFast
         const int y = base + tid;
         int c = 0;
         if (y < L.h) {
@@ -108,7 +111,7 @@ __device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const Le
             }
         }
         int tot;
-        const int ex = block_excl_scan(c, tot, sWave) + carry;
+        const int ex = block_excl_scan<NT>(c, tot, sWave) + carry;
         if (c > 0 && ex < nFast && ex + c >= nFast) { sRed[0] = y; sRed[1] = nFast - ex; }  // exactly one thread
         carry += tot;
         __syncthreads();
@@ -127,12 +130,12 @@ __device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const Le
     }
     const int th = high ? P->iniTh : P->minTh;  // corner of the pass <=> score >= its threshold
     carry = 0;
-    for (int base = 0; base < L.w; base += kQtThreads) {  // the q-th corner of that row
+    for (int base = 0; base < L.w; base += NT) {  // the q-th corner of that row
         const int x = base + tid;
         int flag = 0;
         if (x > kEdge && x < L.w - kEdge) flag = corner_at_global(img, pitch, x, ys, th) ? 1 : 0;
         int tot;
-        const int ex = block_excl_scan(flag, tot, sWave) + carry;
+        const int ex = block_excl_scan<NT>(flag, tot, sWave) + carry;
         if (flag && ex + 1 == q) sRed[2] = x;
         carry += tot;
         __syncthreads();
@@ -147,8 +150,8 @@ __device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const Le
 // bytes of the per-block HBM slab of the GLOBAL variant (see the carve in the kernel)
 __host__ __device__ constexpr size_t qt_scratch_bytes(int nc) { return (size_t)nc * (8 + 8 + 8 + 4 + 4 + 16 + 4 + 4 + 4 + 1 + 1); }
 
-template <int NC, bool GLOBAL>
-__global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <= 512 ? 8 : 1))) void quadtree_kernel(const PipelineDesc* __restrict__ P,
+template <int NC, bool GLOBAL, int NT = kQtThreads>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NC <= 512 ? 8 : 1))) void quadtree_kernel(const PipelineDesc* __restrict__ P,
                                                              const uint32_t* __restrict__ cand,
                                                              uint16_t* __restrict__ nodeOfAll,
                                                              uint32_t* __restrict__ counters,
@@ -158,8 +161,8 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
                                                              const uint32_t* __restrict__ tileRows,
                                                              uint8_t* __restrict__ scratch)
 {
-    constexpr int IPT = NC / kQtThreads;  // nodes per thread in node-parallel steps
-    static_assert(NC % kQtThreads == 0, "NC must be a multiple of the block size");
+    constexpr int IPT = NC / NT;  // nodes per thread in node-parallel steps
+    static_assert(NC % NT == 0, "NC must be a multiple of the block size");
 
     // Node tables: LDS for the usual per-level budgets (<= 2048 nodes); for the reference's large
     // configurations (e.g. 10000 features in one level, mono_inertial_node.cpp:87-93) the same
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
         sSplit = base; base += NC;
         sNch = base;
     }
-    __shared__ int sWave[kQtThreads / 64];
+    __shared__ int sWave[NT / 64];
     __shared__ int sRed[4];
 
     const int f = blockIdx.x, l = blockIdx.y;
@@ -222,20 +225,20 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
     uint32_t cutHi = kKeyInf, cutLo = kKeyInf;
     int cH = (int)cnt[kCntHigh];
     if ((int)cnt[kCntPreHigh] > nFast) {
-        cutHi = pre_nms_cut_key(P, L, f, l, true, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
+        cutHi = pre_nms_cut_key<NT>(P, L, f, l, true, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
         int c = 0;
-        for (int p = tid; p < nAll; p += kQtThreads) c += cand_score(C[p]) >= iniTh && cand_key(C[p]) < cutHi;
-        block_excl_scan(c, cH, sWave);
+        for (int p = tid; p < nAll; p += NT) c += cand_score(C[p]) >= iniTh && cand_key(C[p]) < cutHi;
+        block_excl_scan<NT>(c, cH, sWave);
     }
     // retry rule, src/ORBextractor.cc:440,463-465 (unsigned diff, double compare)
     const unsigned diff = (unsigned)nFast - (unsigned)cH;
     const bool retry = (double)diff > 0.25 * (double)nFast;
     int cL = nAll;
     if (retry && (int)cnt[kCntPreLow] > nFast) {
-        cutLo = pre_nms_cut_key(P, L, f, l, false, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
+        cutLo = pre_nms_cut_key<NT>(P, L, f, l, false, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
         int c = 0;
-        for (int p = tid; p < nAll; p += kQtThreads) c += cand_key(C[p]) < cutLo;
-        block_excl_scan(c, cL, sWave);
+        for (int p = tid; p < nAll; p += NT) c += cand_key(C[p]) < cutLo;
+        block_excl_scan<NT>(c, cL, sWave);
     }
     // (ii) high + low lists together are capped at nFast by trimming the low list's tail (:470-473)
     uint32_t keyCut = cutLo;
@@ -250,9 +253,9 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             int c = 0;
-            for (int p = tid; p < nAll; p += kQtThreads) c += cand_key(C[p]) < mid;
+            for (int p = tid; p < nAll; p += NT) c += cand_key(C[p]) < mid;
             int tot;
-            block_excl_scan(c, tot, sWave);
+            block_excl_scan<NT>(c, tot, sWave);
             if (tot >= lowKept) hi = mid; else lo = mid + 1;
         }
         keyCut = min(lo, cutLo);
@@ -273,9 +276,9 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
     // ---- initial nodes, :231-274 ----
     const int nIni = L.nIni;
     const float hX = L.hX;
-    for (int i = tid; i < NC; i += kQtThreads) sCnt[0][i] = 0;
+    for (int i = tid; i < NC; i += NT) sCnt[0][i] = 0;
     __syncthreads();
-    for (int p = tid; p < cL; p += kQtThreads) {
+    for (int p = tid; p < cL; p += NT) {
         const uint32_t cw = C[p];
         const int wgt = PT_WEIGHT(cw);
         if (wgt) atomicAdd(&sCnt[0][(int)((float)cand_x(cw) / hX)], wgt);
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
     }
     __syncthreads();
     int n = sRed[0];
-    for (int p = tid; p < cL; p += kQtThreads) {
+    for (int p = tid; p < cL; p += NT) {
         const uint32_t cw = C[p];
         if (PT_WEIGHT(cw)) nodeOf[p] = (uint16_t)sKeep[(int)((float)cand_x(cw) / hX)];
     }
@@ -320,23 +323,23 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
         int* nncnt = cur ? sCnt[0] : sCnt[1];
 
         // 1. child counts
-        for (int i = tid; i < n * 4; i += kQtThreads) sCC[i] = 0;
+        for (int i = tid; i < n * 4; i += NT) sCC[i] = 0;
         __syncthreads();
         // (four candidate words and node labels in flight per thread: the passes over the candidates are
         // latency-bound, and a load / use pair per iteration would wait for every L2 round trip in turn)
-        for (int p0 = tid; p0 < cL; p0 += 4 * kQtThreads) {
+        for (int p0 = tid; p0 < cL; p0 += 4 * NT) {
             uint32_t cw4[4];
             int nd4[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int p = p0 + k * kQtThreads;
+                const int p = p0 + k * NT;
                 cw4[k] = p < cL ? C[p] : 0u;
                 nd4[k] = p < cL ? (int)nodeOf[p] : 0;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t cw = cw4[k];
-                const int wgt = (p0 + k * kQtThreads < cL) ? PT_WEIGHT(cw) : 0;
+                const int wgt = (p0 + k * NT < cL) ? PT_WEIGHT(cw) : 0;
                 if (wgt) {
                     const int i = nd4[k];
                     if (ncnt[i] > 1) atomicAdd(&sCC[4 * i + child_code(box[i], cand_x(cw), cand_y(cw))], wgt);
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
             int loc = 0;
 #pragma unroll
             for (int k = 0; k < IPT; k++) loc += myNch[k];
-            int base = block_excl_scan(loc, T, sWave);
+            int base = block_excl_scan<NT>(loc, T, sWave);
 #pragma unroll
             for (int k = 0; k < IPT; k++) {
                 const int i = tid * IPT + k;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
 #pragma unroll
             for (int k = 0; k < IPT; k++) locM += myExp[k];
             int m;
-            block_excl_scan(locM, m, sWave);
+            block_excl_scan<NT>(locM, m, sWave);
 #pragma unroll
             for (int k = 0; k < IPT; k++) {
                 const int i = tid * IPT + k;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
                 locSum += locInc[k];
             }
             int totInc;
-            int run = block_excl_scan(locSum, totInc, sWave);
+            int run = block_excl_scan<NT>(locSum, totInc, sWave);
             int myJ = m;  // candidate: first rank where the inclusive running size >= N
 #pragma unroll
             for (int k = 0; k < IPT; k++) {
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
                 locN[k] = (r < J) ? (int)sNch[sProc[r]] : 0;
                 locT += locN[k];
             }
-            int base = block_excl_scan(locT, T, sWave);
+            int base = block_excl_scan<NT>(locT, T, sWave);
 #pragma unroll
             for (int k = 0; k < IPT; k++) {
                 const int r = tid * IPT + k;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
             locK += (i < n && !sSplit[i]) ? 1 : 0;
         }
         int K;
-        int kbase = block_excl_scan(locK, K, sWave);
+        int kbase = block_excl_scan<NT>(locK, K, sWave);
         const int newSize = T + K;
         if (newSize > NC) overflow = true;  // uniform over the block (T, K are block-wide totals)
         if (overflow) break;
@@ -503,18 +506,18 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
         const int nToExpand = sRed[2];
 
         // 6. re-label the points
-        for (int p0 = tid; p0 < cL; p0 += 4 * kQtThreads) {
+        for (int p0 = tid; p0 < cL; p0 += 4 * NT) {
             uint32_t cw4[4];
             int nd4[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int p = p0 + k * kQtThreads;
+                const int p = p0 + k * NT;
                 cw4[k] = p < cL ? C[p] : 0u;
                 nd4[k] = p < cL ? (int)nodeOf[p] : 0;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int p = p0 + k * kQtThreads;
+                const int p = p0 + k * NT;
                 const uint32_t cw = cw4[k];
                 if (p < cL && PT_WEIGHT(cw)) {
                     const int i = nd4[k];
@@ -540,14 +543,14 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
     // ---- best point per node: max response, first (smallest raster key) wins ties, :515-527 ----
     int* bestResp = sCC;
     uint32_t* bestKey = reinterpret_cast<uint32_t*>(sCC + NC);
-    for (int i = tid; i < n; i += kQtThreads) { bestResp[i] = 0; bestKey[i] = 0xFFFFFFFFu; }
+    for (int i = tid; i < n; i += NT) { bestResp[i] = 0; bestKey[i] = 0xFFFFFFFFu; }
     __syncthreads();
-    for (int p = tid; p < cL; p += kQtThreads) {
+    for (int p = tid; p < cL; p += NT) {
         const uint32_t cw = C[p];
         if (PT_WEIGHT(cw)) atomicMax(&bestResp[nodeOf[p]], cand_score(cw));
     }
     __syncthreads();
-    for (int p = tid; p < cL; p += kQtThreads) {
+    for (int p = tid; p < cL; p += NT) {
         const uint32_t cw = C[p];
         if (PT_WEIGHT(cw)) {
             const int i = nodeOf[p];
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(kQtThreads) __attribute__((amdgpu_waves_per_eu(NC <
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += kQtThreads) out[i] = ((uint32_t)bestResp[i] << 24) | bestKey[i];
+    for (int i = tid; i < n; i += NT) out[i] = ((uint32_t)bestResp[i] << 24) | bestKey[i];
     if (tid == 0) cnt[kCntKp] = (uint32_t)n;
 #undef PT_WEIGHT
 }
@@ -581,8 +584,20 @@ void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, con
                      const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws,
                      const uint32_t* tileRows, uint8_t* scratch)
 {
-    dim3 block(kQtThreads);
     dim3 grid(frames, nLevels);
+    // A call on one or a few frames is a handful of blocks on an empty chip and its time is the largest level's block:
+    // 1024 threads walk every candidate loop in half the trips (0.5 candidates-per-thread passes dominate a level-0 block).
+    if ((long long)frames * nLevels <= 64 && quadtree_node_capacity(maxNodeCap) <= 2048) {
+        dim3 blockS(kQtThreadsSmall);
+        if (quadtree_node_capacity(maxNodeCap) <= 1024)
+            hipLaunchKernelGGL((quadtree_kernel<1024, false, kQtThreadsSmall>), grid, blockS, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
+                               gray0FrameStride, gray0Pitch, ws, tileRows, scratch);
+        else
+            hipLaunchKernelGGL((quadtree_kernel<2048, false, kQtThreadsSmall>), grid, blockS, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
+                               gray0FrameStride, gray0Pitch, ws, tileRows, scratch);
+        return;
+    }
+    dim3 block(kQtThreads);
 #define ORBFE_QT(NCV, GLB)                                                                                        \
     hipLaunchKernelGGL((quadtree_kernel<NCV, GLB>), grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0, \
                        gray0FrameStride, gray0Pitch, ws, tileRows, scratch)
