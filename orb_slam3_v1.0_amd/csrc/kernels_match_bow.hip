@@ -425,7 +425,7 @@ int bow_track_launch(hipStream_t s, const BowTrackArgs& A, std::string& err)
         return ORBFE_ERR_UNSUPPORTED;
     }
     const dim3 blk(256);
-    hipLaunchKernelGGL(fill_kernel, dim3((A.cap + 255) / 256), blk, 0, s, A.matchOut, -1, (size_t)A.cap);
+    // (A.matchOut arrives filled with -1: the vocabulary descent that runs before this wrote it)
     const size_t lds = (size_t)kBowNodeCap * (2 * sizeof(uint4) + sizeof(float)) + (size_t)A.cap * (sizeof(int) + sizeof(uint16_t));
     hipLaunchKernelGGL(bow_track_kernel, dim3(512), dim3(64), lds, s, A);
     hipLaunchKernelGGL(bow_track_finalize_kernel, dim3(1), blk, 0, s, A);

@@ -400,4 +400,106 @@ void launch_pyramid_level(hipStream_t s, int frames, const PipelineDesc* dP, int
                        gray0FrameStride, gray0Pitch, ws, tabs);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small launches (one to eight frames): several levels per launch.
+// A level is resized from the level below it, so the pyramid of a single frame is a chain of seven dependent launches,
+// each a few microseconds of latency on an otherwise idle chip (tools/stage_b1.py: 28 us for the seven, as much as FAST).
+// Here one launch produces up to three consecutive levels l0+1 .. l0+depth from level l0: a pixel of level l0+k is
+// computed from level l0 directly, re-evaluating the (2 x 2)^(k-1) pixels of the levels in between that it depends on
+// with exactly the arithmetic of resize_kernel (same tables, same 11-bit weights, same rounding: the intermediate values
+// are the bytes the other threads store for those levels).  The recomputation -- a factor 4 per skipped level -- is
+// irrelevant for a few frames and would be waste for many: the batched path keeps one row-streaming launch per level.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ChainCtx {
+    const uint8_t* src0;  // level l0 of this frame
+    int pitch0, w0, h0;
+    const uint32_t* xtab[3];
+    const uint32_t* ytab[3];
+    int w[3], h[3];       // sizes of levels l0+1 .. l0+3
+};
+
+// pixel (x, y) of level l0 + K
+template <int K>
+__device__ __forceinline__ uint32_t chain_px(const ChainCtx& c, int x, int y)
+{
+    const uint32_t xt = c.xtab[K - 1][x], yt = c.ytab[K - 1][y];
+    const int sw = K == 1 ? c.w0 : c.w[K - 2], sh = K == 1 ? c.h0 : c.h[K - 2];
+    const int x1 = (int)(xt & 0xffffu), y1 = (int)(yt & 0xffffu);
+    const uint32_t wx = xt >> 16, wy = yt >> 16;
+    const uint32_t wxc = 2048u - wx, wyc = 2048u - wy;
+    const int x2 = min(x1 + 1, sw - 1), y2 = min(y1 + 1, sh - 1);
+    uint32_t a, b, cc, e;
+    if constexpr (K == 1) {
+        const uint8_t* r1 = c.src0 + (size_t)y1 * c.pitch0;
+        const uint8_t* r2 = c.src0 + (size_t)y2 * c.pitch0;
+        a = r1[x1]; b = r1[x2]; cc = r2[x1]; e = r2[x2];
+    } else {
+        a = chain_px<K - 1>(c, x1, y1); b = chain_px<K - 1>(c, x2, y1);
+        cc = chain_px<K - 1>(c, x1, y2); e = chain_px<K - 1>(c, x2, y2);
+    }
+    const uint32_t top = __umul24(a, wxc) + __umul24(b, wx);
+    const uint32_t bot = __umul24(cc, wxc) + __umul24(e, wx);
+    const uint32_t v = __umul24(top, wyc) + __umul24(bot, wy) + (1u << 21);
+    return v >> 22;
+}
+
+// thread -> one pixel of one of the `depth` output levels (adjacent lanes store adjacent bytes); grid.y covers the pixels of
+// all of them.  One pixel per thread keeps the dependent chain of a thread at `depth` rounds of loads.
+__global__ __launch_bounds__(256) void pyramid_chain_kernel(const PipelineDesc* __restrict__ P, int l0, int depth,
+                                                            const uint8_t* __restrict__ gray0, size_t gray0FrameStride, int gray0Pitch,
+                                                            uint8_t* __restrict__ ws, const uint32_t* __restrict__ tabs,
+                                                            uint32_t* __restrict__ zero, int nZeroPerFrame)
+{
+    const int f = blockIdx.x;
+    // the first launch of a chain also clears the frame's per-level counters (FAST, two launches later at the earliest, is
+    // their first user): one node less in the chain than a separate memset
+    if (zero && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < nZeroPerFrame; i += 256) zero[(size_t)f * nZeroPerFrame + i] = 0;
+    ChainCtx c;
+    const LevelDesc& S = P->lv[l0];
+    c.src0 = l0 == 0 ? gray0 + (size_t)f * gray0FrameStride : ws + S.imgOff + (size_t)f * S.imgFrameStride;
+    c.pitch0 = l0 == 0 ? gray0Pitch : S.pitch;
+    c.w0 = S.w;
+    c.h0 = S.h;
+    int np[3] = {0, 0, 0};  // pixels per level
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const LevelDesc& D = P->lv[min(l0 + 1 + k, P->nLevels - 1)];
+        c.xtab[k] = tabs + D.xtabOff;
+        c.ytab[k] = tabs + D.ytabOff;
+        c.w[k] = D.w;
+        c.h[k] = D.h;
+        np[k] = k < depth ? D.w * D.h : 0;
+    }
+    int idx = (int)blockIdx.y * 256 + (int)threadIdx.x;
+    int k = 0;
+    if (idx >= np[0]) { idx -= np[0]; k = 1; if (idx >= np[1]) { idx -= np[1]; k = 2; if (idx >= np[2]) return; } }
+    const LevelDesc& D = P->lv[l0 + 1 + k];
+    const int y = idx / D.w, x = idx - y * D.w;
+    uint32_t out;
+    if (k == 0) out = chain_px<1>(c, x, y);
+    else if (k == 1) out = chain_px<2>(c, x, y);
+    else out = chain_px<3>(c, x, y);
+    ws[D.imgOff + (size_t)f * D.imgFrameStride + (size_t)y * D.pitch + x] = (uint8_t)out;
+}
+
+}  // namespace
+
+// levels l0+1 .. l0+depth (depth 1..3) of `frames` frames in one launch; hostP is the host copy of *dP
+void launch_pyramid_chain(hipStream_t s, int frames, const PipelineDesc* dP, const PipelineDesc& hostP, int l0, int depth,
+                          const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs,
+                          uint32_t* zero, int nZeroPerFrame)
+{
+    long long pixels = 0;
+    for (int k = 0; k < depth; k++) {
+        const LevelDesc& D = hostP.lv[l0 + 1 + k];
+        pixels += (long long)D.w * D.h;
+    }
+    hipLaunchKernelGGL(pyramid_chain_kernel, dim3(frames, (unsigned)((pixels + 255) / 256)), dim3(256), 0, s, dP, l0, depth, gray0,
+                       gray0FrameStride, gray0Pitch, ws, tabs, zero, nZeroPerFrame);
+}
+
 }  // namespace orbfe

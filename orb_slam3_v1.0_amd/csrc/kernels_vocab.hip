@@ -26,10 +26,13 @@ __global__ __launch_bounds__(256) void vocab_transform_kernel(const int* __restr
                                                               const uint8_t* __restrict__ nodeDesc, const int* __restrict__ wordId,
                                                               const uint8_t* __restrict__ desc, int n, const int* __restrict__ nDev,
                                                               int nidLevel, int* __restrict__ out /* [n][2]: word id, node id */,
-                                                              int* __restrict__ leafOut /* [n]: leaf node (weight lookup) */)
+                                                              int* __restrict__ leafOut /* [n]: leaf node (weight lookup) */,
+                                                              int* __restrict__ clearOut /* optional [capacity]: set to -1 */)
 {
     const int gid = (blockIdx.x * 256 + threadIdx.x) / G;  // feature
     const int gl = threadIdx.x % G;
+    // (fused per-frame chain: the matcher's output array starts as "no match" -- one launch less than a separate fill)
+    if (clearOut && gl == 0 && gid < n) clearOut[gid] = -1;
     if (nDev) n = min(n, *nDev);  // the count is still on the device (fused per-frame chain): n is the capacity
     if (gid >= n) return;  // whole groups exit together (256 % G == 0)
     unsigned long long d4[4];
@@ -143,10 +146,10 @@ int vocab_transform(Vocab* v, hipStream_t s, const uint8_t* desc, int n, int lev
     int* dLeaf = v->dOut + 2 * (size_t)n;
     if (v->maxChildren <= 16)
         hipLaunchKernelGGL(vocab_transform_kernel<16>, dim3((n * 16 + 255) / 256), dim3(256), 0, s, v->dChildOff, v->dChildIdx,
-                           v->dDesc, v->dWordId, v->dIn, n, nullptr, nidLevel, v->dOut, dLeaf);
+                           v->dDesc, v->dWordId, v->dIn, n, nullptr, nidLevel, v->dOut, dLeaf, nullptr);
     else
         hipLaunchKernelGGL(vocab_transform_kernel<64>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, v->dChildOff, v->dChildIdx,
-                           v->dDesc, v->dWordId, v->dIn, n, nullptr, nidLevel, v->dOut, dLeaf);
+                           v->dDesc, v->dWordId, v->dIn, n, nullptr, nidLevel, v->dOut, dLeaf, nullptr);
     VCHK(hipGetLastError());
     VCHK(hipMemcpyAsync(hOut, v->dOut, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     VCHK(hipStreamSynchronize(s));
@@ -161,16 +164,16 @@ int vocab_transform(Vocab* v, hipStream_t s, const uint8_t* desc, int n, int lev
 // the descent on descriptors that are already on the device, their count included (orbfe_track_reference_keyframe: the
 // extraction chain wrote them a kernel earlier); no copy, no synchronisation -- capturable
 int vocab_transform_launch_dev(const Vocab* v, hipStream_t s, const uint8_t* dDesc, const int* dN, int cap, int levelsup,
-                               int* dOut, int* dLeaf, std::string& err)
+                               int* dOut, int* dLeaf, int* dClear, std::string& err)
 {
     if (cap <= 0) return ORBFE_OK;
     const int nidLevel = v->L - levelsup;
     if (v->maxChildren <= 16)
         hipLaunchKernelGGL(vocab_transform_kernel<16>, dim3((cap * 16 + 255) / 256), dim3(256), 0, s, v->dChildOff, v->dChildIdx,
-                           v->dDesc, v->dWordId, dDesc, cap, dN, nidLevel, dOut, dLeaf);
+                           v->dDesc, v->dWordId, dDesc, cap, dN, nidLevel, dOut, dLeaf, dClear);
     else
         hipLaunchKernelGGL(vocab_transform_kernel<64>, dim3((cap * 64 + 255) / 256), dim3(256), 0, s, v->dChildOff, v->dChildIdx,
-                           v->dDesc, v->dWordId, dDesc, cap, dN, nidLevel, dOut, dLeaf);
+                           v->dDesc, v->dWordId, dDesc, cap, dN, nidLevel, dOut, dLeaf, dClear);
     VCHK(hipGetLastError());
     return ORBFE_OK;
 }

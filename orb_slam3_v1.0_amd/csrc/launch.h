@@ -14,6 +14,11 @@ bool pyramid_level_fits(const uint32_t* xtab, const uint32_t* ytab, int sw, int 
 void launch_pyramid_level(hipStream_t s, int frames, const PipelineDesc* dP, int level, int dw, int dh, const uint8_t* gray0,
                           size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs);
 
+// small launches: levels l0+1 .. l0+depth (depth <= 3) from level l0 in ONE launch (intermediate levels re-evaluated per pixel)
+void launch_pyramid_chain(hipStream_t s, int frames, const PipelineDesc* dP, const PipelineDesc& hostP, int l0, int depth,
+                          const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, uint8_t* ws, const uint32_t* tabs,
+                          uint32_t* zero = nullptr, int nZeroPerFrame = 0);  // optional: words to clear per frame (the level counters)
+
 // kernels_fast.hip (FAST + NMS + compaction fused with the Gaussian blur of the same tile)
 void fast_tiles_for(int w, int h, int* tx, int* ty);
 uint32_t fast_tile_info(int level, int tileX, int tileY);  // entry of the per-tile table (level << 24 | ty << 12 | tx)

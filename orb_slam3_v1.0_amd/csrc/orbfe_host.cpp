@@ -580,10 +580,19 @@ static int extract_chain(orbfe_handle* h, const uint8_t* d_gray, size_t frame_st
         h->evHead = (h->evHead + 1) % kEventSets;
         h->evCount++;
     }
-    HIPCHK(h, hipMemsetAsync(h->dCounters, 0, (size_t)batch * nL * kCntWords * sizeof(uint32_t), s));
+    const bool chainPyr = (long long)batch * nL <= 64 && !ev && nL > 1;  // one to eight frames: see below
+    if (!chainPyr) HIPCHK(h, hipMemsetAsync(h->dCounters, 0, (size_t)batch * nL * kCntWords * sizeof(uint32_t), s));
     if (ev) HIPCHK(h, hipEventRecord(ev[0], s));
     // ComputePyramid (:607-623): level l from the UNBLURRED level l-1
-    for (int l = 1; l < nL; l++) {
+    // (one to eight frames: two or three levels per launch -- a dependent launch costs more than the small levels' work)
+    for (int l = 1; chainPyr && l < nL;) {
+        const int left = nL - l;
+        const int depth = left >= 5 ? 2 : std::min(left, 3);  // 7 levels to build: 2 + 2 + 3
+        launch_pyramid_chain(s, batch, h->dP, P, l - 1, depth, d_gray, frame_stride, pitch, h->ws, h->dTabs,
+                             l == 1 ? h->dCounters : nullptr, nL * kCntWords);  // the first launch clears the level counters
+        l += depth;
+    }
+    for (int l = chainPyr ? nL : 1; l < nL; l++) {
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
         if (h->pyrFits[l] && (l > 1 || aligned4)) {
@@ -2451,7 +2460,8 @@ int ref_enqueue(orbfe_handle* h, const RefLayout& L, int inPitch, const orbfe::V
     if (rc != ORBFE_OK) return rc;
     std::string err;
     int* dBow = reinterpret_cast<int*>(h->dRefOut + L.oBow);
-    rc = vocab_transform_launch_dev(v, s, h->dRefOut + L.oDesc, dHead, cap, levelsup, dBow, reinterpret_cast<int*>(h->dRefOut + L.oLeaf), err);
+    rc = vocab_transform_launch_dev(v, s, h->dRefOut + L.oDesc, dHead, cap, levelsup, dBow, reinterpret_cast<int*>(h->dRefOut + L.oLeaf),
+                                    reinterpret_cast<int*>(h->dRefOut + L.oMatch), err);
     if (rc == ORBFE_OK) {
         BowTrackArgs A{};
         A.ref = reinterpret_cast<const BowKfRef*>(h->dRefIn + L.oRef);

@@ -28,7 +28,8 @@ void vocab_destroy(Vocab* v);
 int vocab_transform(Vocab* v, hipStream_t s, const uint8_t* desc, int n, int levelsup, int* wordOut, int* nodeOut,
                     double* weightOut, std::string& err);
 // device descriptors, device count (<= cap); dOut [cap][2] = (word id, node id), dLeaf [cap] = the leaf reached
+// dClear (optional, [cap]): set to -1 by the same launch
 int vocab_transform_launch_dev(const Vocab* v, hipStream_t s, const uint8_t* dDesc, const int* dN, int cap, int levelsup,
-                               int* dOut, int* dLeaf, std::string& err);
+                               int* dOut, int* dLeaf, int* dClear, std::string& err);
 
 }  // namespace orbfe
