@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frus
                                                           const unsigned long long* __restrict__ rightDesc, int nRight,
                                                           int* __restrict__ bestIdxOut, int* __restrict__ bestDistOut)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (one wave per block for a single call: see fuse_search_run)
     if (i >= M) return;
     const orbfe_world_point p = pts[i];
     int bestIdx = -1, bestDist = 256;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void sim3_search_kernel(ProjArgs A, orbfe_sim3
                                                           const orbfe_world_point* __restrict__ pts,
                                                           const uint8_t* __restrict__ mpDesc, int* __restrict__ vnMatch)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const orbfe_world_point p = pts[i];
     int bestIdx = -1;
@@ -379,7 +379,7 @@ int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, 
     A.matchOut = reinterpret_cast<int*>(dp + oMatch);
     proj_prepare_launch(s, A, false);
     int* dBest = reinterpret_cast<int*>(dp + oBest);
-    hipLaunchKernelGGL(fuse_search_kernel, dim3((M + 255) / 256), dim3(256), 0, s, A, *F, th, M,
+    hipLaunchKernelGGL(fuse_search_kernel, dim3((M + 63) / 64), dim3(64), 0, s, A, *F, th, M,
                        reinterpret_cast<const orbfe_world_point*>(dp + oPts), dp + oMpDesc,
                        reinterpret_cast<const float*>(dp + oIs2), uRight ? reinterpret_cast<const float*>(dp + oUr) : nullptr,
                        chi2Gate, nRight >= 0 ? reinterpret_cast<const unsigned long long*>(dp + oRight) : nullptr, nRight, dBest,
@@ -506,9 +506,9 @@ int search_by_sim3_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* K
     int* vn2 = reinterpret_cast<int*>(dp + oVn2);
     int* dOut = reinterpret_cast<int*>(dp + oOut);
     // key frame 1's map points into key frame 2 (tables A2), then the other way round
-    hipLaunchKernelGGL(sim3_search_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, A2, *d12, th, n1,
+    hipLaunchKernelGGL(sim3_search_kernel, dim3((n1 + 63) / 64), dim3(64), 0, s, A2, *d12, th, n1,
                        reinterpret_cast<const orbfe_world_point*>(dp + oP1), dp + oD1, vn1);
-    hipLaunchKernelGGL(sim3_search_kernel, dim3((n2 + 255) / 256), dim3(256), 0, s, A1, *d21, th, n2,
+    hipLaunchKernelGGL(sim3_search_kernel, dim3((n2 + 63) / 64), dim3(64), 0, s, A1, *d21, th, n2,
                        reinterpret_cast<const orbfe_world_point*>(dp + oP2), dp + oD2, vn2);
     MCHK(hipMemsetAsync(dOut + n1, 0, sizeof(int), s));
     hipLaunchKernelGGL(sim3_agree_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, n1, vn1, vn2, dOut, dOut + n1);

@@ -189,7 +189,7 @@ __device__ inline bool kb8_epipolar(const CamP& C1, const CamP& C2, float precis
 
 __global__ __launch_bounds__(256) void tri_match_kernel(TriArgs A)
 {
-    const int pos = blockIdx.x * 256 + threadIdx.x;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= A.nPos1) return;
     const int idx1 = A.idx1[pos];
     if (A.hasMP1[idx1]) return;  // :506-509
@@ -515,7 +515,7 @@ int match_triangulation_run(MatchScratch& m, hipStream_t s, int G, const int* of
     A.nMatches = reinterpret_cast<int*>(dp + oNM);
     const dim3 blk(256);
     hipLaunchKernelGGL(fill_kernel, dim3((n1 + 255) / 256), blk, 0, s, A.match12, -1, (size_t)n1);
-    hipLaunchKernelGGL(tri_match_kernel, dim3((nPos1 + 255) / 256), blk, 0, s, A);
+    hipLaunchKernelGGL(tri_match_kernel, dim3((nPos1 + 63) / 64), dim3(64), 0, s, A);
     hipLaunchKernelGGL(tri_finalize_kernel, dim3(1), blk, 0, s, A);
     MCHK(hipGetLastError());
     int* hMatch = reinterpret_cast<int*>(hp + inBytes);
