@@ -717,7 +717,7 @@ static void graph_capture_failed(orbfe_handle* h)
 }
 
 // extract_host_enqueue, replayed from a hipGraph when possible: every pointer behind the upload is owned by the
-// handle, so the enqueue sequence (memset, 10 kernels, result copy) is captured once per (batch, input pitch) and
+// handle, so the enqueue sequence (the kernels of extract_chain, result copy) is captured once per (batch, input pitch) and
 // replayed with a single hipGraphLaunch
 static int extract_enqueue_replay(orbfe_handle* h, int batch, int inPitch, hipStream_t s)
 {
@@ -725,7 +725,7 @@ static int extract_enqueue_replay(orbfe_handle* h, int batch, int inPitch, hipSt
     int rc = ORBFE_OK;
     bool viaGraph = h->useGraph && !h->timing && batch < 4096;
     if (viaGraph) {
-        // every pointer behind the upload is owned by the handle, so the enqueue sequence (memset, 10 kernels, result
+        // every pointer behind the upload is owned by the handle, so the enqueue sequence (kernels, result
         // copy) is captured once per batch size and replayed with a single hipGraphLaunch
         const int gkey = batch | (inPitch << 12);  // batch <= 4095 frames per call in graph mode, else plain launches
         hipGraphExec_t& exec = h->graphs[gkey];
