@@ -18,7 +18,13 @@ There is no data-path collective; `config.gather_bytes_per_step` says what each 
 
 Prints ONE JSON line on rank 0 (driver contract), including
   roofline      dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s, plus the instruction
-                side (`issue`) and the PMC traffic of the committed profile of the SAME sources (`profiles_head`)
+                side (`issue`: priced at the clock MEASURED in this run) and the PMC traffic / VALU-busy share of the committed
+                profile of the SAME sources (`profiles_head`)
+  sustained     a second timed region behind the driver's K steps: the same step loop for >= 5 s, every step's duration from HIP
+                events (p50 / p99 / max), the first and the last 100 steps, and the shader clock the chip held meanwhile, read in
+                the kernel (s_memtime over s_memrealtime, orbfe_debug_clock_probe) on a stream beside the workload
+  verified      8 frames of the LAST timed step's device buffers re-computed by the CPU oracle: keypoints + descriptors and the
+                match indices must be equal byte for byte, or the exit code is non-zero
   cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) pinned to one host core
   latency       the reference's own call shape -- ONE host frame per call (src/Frame.cc:178-189): orbfe_extract from
                 pageable and pinned memory, orbfe_match_projection (2000 map points), orbfe_prepare_and_extract, each
@@ -46,11 +52,13 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0  # same guide: measured copy peak
-SIMDS, CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, max clock
+SIMDS, CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32; 2.4 GHz = max clock (the fallback when no clock could be measured)
 
 WORKLOADS = {
     # name: (nFeatures, nFast, scale, levels, iniTh, minTh, W, H)   [SURVEY.md section 8 S0 defaults]
     "euroc_752x480": (1000, 40000, 1.2, 8, 20, 7, 752, 480),
+    # SURVEY.md section 8, SPEC DECISION S0: nFastFeatures = 16 x nFeatures (the default above is 40 x: no cap ever fires)
+    "euroc_752x480_s0": (1000, 16000, 1.2, 8, 20, 7, 752, 480),
     "batched_1280x720": (2000, 100000, 1.2, 8, 20, 7, 1280, 720),
     "tumvi_1024x1024": (1500, 100000, 1.2, 12, 20, 7, 1024, 1024),
 }
@@ -239,7 +247,8 @@ class StepRunner:
     def _on(self, stream):
         return torch.cuda.stream(stream) if self.cuda else contextlib.nullcontext()
 
-    def step(self, timed=False):
+    def step(self, timed=False, done_event=None):
+        """one step; done_event (optional, timing-enabled) is recorded where the step's last piece of work is enqueued"""
         b = self.bufs[self.count % self.nbuf]
         fs = self.count % self.frame_sets
         self.count += 1
@@ -271,7 +280,36 @@ class StepRunner:
                 self.dist.all_gather_into_tensor(self.g_cnt, self.cnt)
         if self.nbuf == 2:
             b["ev_done"].record(self.s2)
+        if done_event is not None:
+            done_event.record(self.s2)  # (s2 is s1 when the step runs on one stream)
+        self.last = (b, fs)
         return b
+
+    def verify_gather(self):
+        """after the last step, stream idle: this rank's slots of the gathered arrays must hold exactly what it packed, and
+        every rank must hold the same gathered bytes (a byte sum compared through MAX / MIN all-reduces).  -> (slots of this
+        rank that differ, gathered bytes identical on all ranks) or None when no collective ran"""
+        if self.gather == "none":
+            return None
+        r = self.dist.get_rank() if self.dist is not None else 0
+        lo, hi = r * self.B, (r + 1) * self.B
+        b = self.last[0]
+        if self.gather == "full":
+            want = torch.cat([b["kp"], b["desc"], b["match"].view(torch.uint8).reshape(self.B, self.cap, 4)], dim=2)
+            bad = int((self.g_out[lo:hi] != want).any(dim=2).sum().item()) + int((self.g_n[lo:hi] != b["n"]).sum().item())
+            digest = self.g_out.sum(dtype=torch.int64) + 131 * self.g_n.sum(dtype=torch.int64)
+        else:
+            want = torch.stack([b["n"], b["nmatch"]], dim=1)
+            bad = int((self.g_cnt[lo:hi] != want).any(dim=1).sum().item())
+            digest = (self.g_cnt.to(torch.int64) * torch.tensor([1, 65537], dtype=torch.int64, device=self.dev)).sum()
+        t = torch.stack([digest, -digest, torch.tensor(bad, dtype=torch.int64, device=self.dev)])
+        if self.dist is not None:
+            mx = t.clone()
+            self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
+            sm = t[2:].clone()
+            self.dist.all_reduce(sm, op=self.dist.ReduceOp.SUM)
+            return int(sm[0].item()), bool(mx[0].item() == -mx[1].item())
+        return bad, True
 
     def gather_bytes_per_step(self):
         """bytes every GPU RECEIVES per step through the collective"""
@@ -383,6 +421,115 @@ def host_io_match_rate(ex, frames, slot_frames, rounds):
     return best, stats["matches"] / max(1, stats["frames"])
 
 
+def _pct(v, q):
+    return float(np.percentile(np.asarray(v, np.float64), q))
+
+
+def sustained_run(runner, ex, dev, dist, frames_total, seconds, est_step_s, rank, world):
+    """The same step loop as the headline region, for >= `seconds` of wall time: one HIP event behind every step (its
+    duration = the distance to the previous step's event), and every ~1/64th of the run one clock probe
+    (orbfe_debug_clock_probe, 20 us, one wave) on a stream of its own released by that step's event, so the probes are
+    spread over the region and read the clock the extraction kernels run at.  Wall time between barriers, MAX over ranks, like
+    the headline.  The reference's cadence is a continuous stream (mono_inertial_node.cpp:207), not a burst."""
+    n_steps = max(200, int(np.ceil(seconds * 1.04 / max(est_step_s, 1e-6))))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+    every = max(1, n_steps // 64)
+    probes = torch.zeros((n_steps // every + 4, 2), dtype=torch.int64, device=dev)
+    s3 = torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    ex.clock_probe(probes[0].data_ptr(), 20, s3.cuda_stream)  # the clock of the idle chip, for comparison
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    evs[0].record(runner.s2)
+    k = 1
+    for i in range(n_steps):
+        runner.step(done_event=evs[i + 1])
+        if i % every == every // 2:
+            s3.wait_event(evs[i + 1])
+            ex.clock_probe(probes[k].data_ptr(), 20, s3.cuda_stream)
+            k += 1
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt_local = dt = time.perf_counter() - t0
+    d_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)], np.float64)
+    p50 = _pct(d_ms, 50)
+    per_rank = [p50]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0].item())
+        g = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(g, torch.tensor([p50], dtype=torch.float64, device=dev))
+        per_rank = [float(x) for x in g.tolist()]
+    pr = probes[:k].cpu().numpy().astype(np.float64)
+    mhz = pr[:, 0] / np.maximum(pr[:, 1], 1.0) * 100.0  # shader cycles per 100 MHz tick (MI355X_MICROARCH.md, DVFS item 6)
+    run = mhz[1:]
+    hundred = min(100, n_steps // 2)
+    return {"seconds": dt, "steps": n_steps, "value": frames_total * n_steps / dt, "unit": "frames/s",
+            "ms_per_step": {"p50": p50, "p99": _pct(d_ms, 99), "max": float(d_ms.max()), "min": float(d_ms.min()),
+                            "mean": float(d_ms.mean()), "wall_over_steps": dt_local / n_steps * 1e3},
+            "first_100_steps_value": frames_total * hundred / (d_ms[:hundred].sum() * 1e-3),
+            "last_100_steps_value": frames_total * hundred / (d_ms[-hundred:].sum() * 1e-3),
+            "per_rank_p50_ms": per_rank,
+            "sclk_mhz": {"start": float(np.median(run[:3])) if len(run) else None, "end": float(np.median(run[-3:])) if len(run) else None,
+                         "min": float(run.min()) if len(run) else None, "max": float(run.max()) if len(run) else None,
+                         "mean": float(run.mean()) if len(run) else None, "idle_before": float(mhz[0]), "probes": int(len(run)),
+                         "method": "in-kernel: delta s_memtime / delta s_memrealtime x 100 MHz over 20 us, one wave on its own stream "
+                                   "beside the workload (rank 0's GPU)"},
+            "what": "step durations and first/last-100 figures are rank %d's (event to event on the stream the step ends on); "
+                    "`value` = all ranks' frames / MAX-over-ranks wall time of the region" % rank}
+
+
+def verify_last_step(runner, frames_host, state, B, cap, M, cfg, n_frames=8):
+    """The headline says bit-exact: take `n_frames` frames spread over the batch of the LAST step that ran (whatever timed region
+    that was), run the CPU oracle on the same frames and the same map points, and compare the device buffers byte for byte.
+    The oracle is the checker here, outside every timed region (src/ORBextractor.cc:543-585, src/ORBmatcher.cc:31-123)."""
+    import oracle_py as O
+    import orbfe
+    b, fs = runner.last
+    W, H = cfg[6], cfg[7]
+    idx = sorted(set(int(round(x)) for x in np.linspace(0, B - 1, min(n_frames, B))))
+    sel = torch.tensor(idx, device=b["n"].device)
+    n_h = b["n"][sel].cpu().numpy()
+    kp_h = b["kp"][sel].cpu().numpy().reshape(len(idx), cap * 24).view(orbfe.KP_DTYPE).reshape(len(idx), cap)
+    desc_h = b["desc"][sel].cpu().numpy()
+    ref = O.Extractor(*cfg)
+    kp_ok = match_ok = True
+    first_bad = None
+    if M:
+        match_h = b["match"][sel].cpu().numpy()
+        nm_h = b["nmatch"][sel].cpu().numpy()
+        mps_h = state["mps"][fs].cpu().numpy().view(orbfe.MP_DTYPE).reshape(-1, M)
+        mpd_h = state["mpd"][fs].cpu().numpy().reshape(-1, M, 32)
+    for j, i in enumerate(idx):
+        kp_r, desc_r, _ = ref.extract(frames_host[fs][i])
+        n = int(n_h[j])
+        same = n == len(kp_r) and kp_h[j, :n].tobytes() == kp_r.tobytes() and np.array_equal(desc_h[j, :n], desc_r)
+        kp_ok &= bool(same)
+        if M:
+            if len(kp_r):
+                fv = O.make_frame_view(kp_r, desc_r, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors)
+                nm_r, match_r = O.search_by_projection(fv, mps_h[i].view(O.MP_DTYPE), mpd_h[i], None, MATCH_TH, MATCH_NN)
+            else:
+                nm_r, match_r = 0, np.zeros(0, np.int32)
+            msame = same and int(nm_h[j]) == nm_r and np.array_equal(match_h[j, :n], match_r)
+            match_ok &= bool(msame)
+            same = same and msame
+        if not same and first_bad is None:
+            first_bad = i
+    out = {"frames": len(idx), "frame_indices": idx, "frame_set": fs, "kp_desc_equal": kp_ok,
+           "checker": "CPU oracle (oracle/, single thread) on the same frames%s, after the timed regions" % (" and map points" if M else "")}
+    if M:
+        out["match_equal"] = match_ok
+    if first_bad is not None:
+        out["first_mismatch_frame"] = first_bad
+    return out
+
+
 def launch_ranks(n, argv):
     """`bench.py --gpus N` started as ONE process: start N ranks (one per GPU) through torch.distributed.run on
     127.0.0.1 and relay rank 0's JSON line.  The parent never initialises the GPU (no torch.cuda call, no HIP call): the
@@ -448,7 +595,92 @@ def _median_ms(fn, reps, warm=5):
     return float(np.median(ts)) * 1e3
 
 
-def latency_block(cfg, device_index, frames, reps=200):
+def _dist_ms(fn, reps, warm=20):
+    """p50 / p99 / max (and mean) of `reps` calls in ms: what a 20 Hz real-time consumer budgets against"""
+    for _ in range(warm):
+        fn()
+    ts = np.empty(reps, np.float64)
+    for i in range(reps):
+        t = time.perf_counter()
+        fn()
+        ts[i] = time.perf_counter() - t
+    ts *= 1e3
+    return {"p50": _pct(ts, 50), "p99": _pct(ts, 99), "p999": _pct(ts, 99.9), "max": float(ts.max()), "mean": float(ts.mean()), "calls": int(reps)}
+
+
+class MappingLoad:
+    """The reference runs LocalMapping::Run on its own thread beside the tracking thread (src/System.cc; src/LocalMapping.cc:66-110):
+    this context runs the mapping thread's calls in a loop on ITS OWN handle -- a new key frame uploaded (orbfe_keyframe_create),
+    SearchForTriangulation against K = 20 resident neighbours in one launch (orbfe_match_triangulation_batch), a Fuse search
+    against a key frame (orbfe_fuse_search, 2000 map points) and ComputeDistinctiveDescriptors for 200 map points -- while the
+    caller measures the tracking thread's latency.  ctypes releases the GIL inside every call."""
+
+    def __init__(self, cfg, device_index, frame):
+        import threading
+        import orbfe
+        import oracle_py as O
+        import frustum_scenarios as FS
+        import test_distinct
+        import test_fuse
+        import test_triangulation_batch as TB
+        from test_frustum import ON, PN
+        self.ex = orbfe.ORBextractor(*cfg, device=device_index, max_batch=1)
+        self.m = orbfe.ORBmatcher(self.ex)
+        ex = self.ex
+        kp, desc = ex.extractFeatures(frame)
+        kpo = kp.view(O.KP_DTYPE)
+        W, H = cfg[6], cfg[7]
+        node1 = TB.nodes_of(kpo)
+        K = 20
+        nbs = [TB.neighbour(kpo, desc, 500 + k, True, False) for k in range(K)]
+        self.kf2 = [orbfe.KeyFrame(ex, nb["kp"].view(orbfe.KP_DTYPE), nb["desc"], nb["node"], ex.mvScaleFactor) for nb in nbs]
+        self.prm = [orbfe.tri_params(nb["F12"], nb["ep"], False, False, True) for nb in nbs]
+        self.has2 = [nb["has"] for nb in nbs]
+        self.has1 = (np.random.default_rng(9).random(len(kp)) < 0.3).astype(np.uint8)
+        Fo, self.Fp = O.Frustum(), orbfe.Frustum()
+        v = FS.fill_frustum(Fo, ON, W=float(W), H=float(H), n_levels=ex.nlevels, scale=cfg[2], seed=3)
+        FS.fill_frustum(self.Fp, PN, W=float(W), H=float(H), n_levels=ex.nlevels, scale=cfg[2], seed=3)
+        pts, self.fmpd, _, self.inv_s2 = test_fuse.scenario(kpo, desc, ex.mvScaleFactor, v, N_MAP_POINTS, 1, False)
+        self.pts = pts.view(orbfe.WP_DTYPE)
+        self.fv = orbfe.make_frame_view(kp, desc, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+        self.doff, self.ddesc = test_distinct.make_sets(3, [int(x) for x in np.random.default_rng(0).integers(2, 20, 200)])
+        self.kp, self.desc, self.node1 = kp, desc, node1
+        self.stop, self.rounds, self.err = threading.Event(), 0, None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _round(self):
+        import orbfe
+        ex = self.ex
+        kf1 = orbfe.KeyFrame(ex, self.kp, self.desc, self.node1, ex.mvScaleFactor)
+        orbfe.SearchForTriangulation_batch(ex, kf1, self.has1, self.kf2, self.has2, self.prm)
+        kf1.close()
+        self.m.Fuse_search(self.fv, self.inv_s2, None, self.Fp, 3.0, self.pts, self.fmpd)
+        self.m.ComputeDistinctiveDescriptors(self.doff, self.ddesc)
+
+    def _run(self):
+        try:
+            while not self.stop.is_set():
+                self._round()
+                self.rounds += 1
+        except Exception as e:  # noqa: BLE001 -- reported by the caller
+            self.err = e
+
+    def __enter__(self):
+        self._round()  # arenas grown, kernels loaded before the measurement starts
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.thread.join(timeout=60)
+        for k in self.kf2:
+            k.close()
+        self.ex.close()
+        if self.err is not None and exc[0] is None:
+            raise self.err
+
+
+def latency_block(cfg, device_index, frames, reps=200, tail_calls=5000):
     """The reference's call shape: ONE host image per call (src/Frame.cc:178-189: ExtractORB on the frame the node hands
     over at 20 Hz, ros2_ws/src/mono-inertial/src/mono_inertial_node.cpp:207), then one SearchByProjection
     (src/Tracking.cc:1115), and the node-side preparation + extraction chain (image_grabber.hpp:96-110).  Wall time per
@@ -543,6 +775,38 @@ def latency_block(cfg, device_index, frames, reps=200):
     out["track_frame_equals_oracle"] = bool(n_o == got["nmatches"] and np.array_equal(match_o, got["match"]))
     out["track_frame_oracle_ms"] = _median_ms(oracle_chain, 10, 1)
     mp_res.close()
+    if tail_calls > 0:
+        # ---- tail latency of the two per-frame chains (src/Tracking.cc:152-173,925-930 / :825-835), alone and beside the mapping
+        #      thread (src/LocalMapping.cc:66-110) on its own handle ----
+        import vocab_synth as vs
+        tvoc = vs.spread_first_level(vs.make_tree(10, 6, seed=17, early_leaf_p=0.02), 18)  # ORBvoc's shape: k = 10, L = 6
+        voc = orbfe.ORBVocabulary(ex1, tvoc["childOff"], tvoc["childIdx"], tvoc["nodeDesc"], tvoc["wordId"], tvoc["weight"], 6)
+        _, node_kf, w_kf = voc.transform(desc, 4)
+        kf_res = orbfe.KeyFrame(ex1, kp, desc, np.where(w_kf > 0, node_kf, -1).astype(np.int32), ex1.mvScaleFactor)
+        has_kf = (np.random.default_rng(4).random(len(kp)) < 0.8).astype(np.uint8)
+
+        def ref_chain():
+            it["i"] += 1
+            return trk.TrackReferenceKeyFrame(pinned[it["i"] % len(pinned)], voc, 4, kf_res, has_kf, 0.75, True)
+
+        out["track_reference_keyframe_matches"] = int(ref_chain()["nmatches"])
+        tail = {"unit": "ms per call", "alone": {"track_frame": _dist_ms(fused(pinned), tail_calls),
+                                                  "track_reference_keyframe": _dist_ms(ref_chain, tail_calls)}}
+        with MappingLoad(cfg, device_index, pageable[0]) as load:
+            r0, t0 = load.rounds, time.perf_counter()
+            tail["loaded"] = {"track_frame": _dist_ms(fused(pinned), tail_calls),
+                              "track_reference_keyframe": _dist_ms(ref_chain, tail_calls)}
+            tail["mapping_rounds_per_s"] = (load.rounds - r0) / (time.perf_counter() - t0)
+        tail["what"] = ("%d calls each from pinned frames; `loaded` = the same calls while a second thread on its OWN handle loops over "
+                        "the mapping thread's calls (orbfe_keyframe_create + orbfe_match_triangulation_batch K = 20 + orbfe_fuse_search "
+                        "%d map points + orbfe_distinctive_descriptors 200 sets; mapping_rounds_per_s of them ran meanwhile)" % (
+                            tail_calls, N_MAP_POINTS))
+        out["tail"] = tail
+        out["track_frame_ms_p99"] = {"alone": tail["alone"]["track_frame"]["p99"], "loaded": tail["loaded"]["track_frame"]["p99"]}
+        out["track_reference_keyframe_ms_p99"] = {"alone": tail["alone"]["track_reference_keyframe"]["p99"],
+                                                  "loaded": tail["loaded"]["track_reference_keyframe"]["p99"]}
+        kf_res.close()
+        voc.close()
     # node-side chain at the node's own configuration (mono_inertial_node.cpp:20,59-71): 2048x1536 BGR -> 614x460 grey -> extract
     SW, SH, DW, DH = 2048, 1536, 614, 460
     pcfg = (cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], DW, DH)
@@ -592,9 +856,12 @@ def launcher_selftest(a, rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if dist.get_world_size() != a.gpus:
         raise SystemExit("selftest: --gpus %d but the process group has %d ranks" % (a.gpus, dist.get_world_size()))
+    gv = r.verify_gather()  # this rank's slots of the gathered arrays == what it packed; the same bytes on every rank
     if rank == 0:
         counts = r.g_cnt.view(world, B, 2).tolist() if mode == "counts" else None
         print(json.dumps({"metric": "selftest", "value": 0.0, "unit": "none", "n_gpus": dist.get_world_size(), "steps": a.steps,
+                          "gather_verified": None if gv is None else {"mismatching_slots_all_ranks": gv[0], "identical_on_all_ranks": gv[1],
+                                                                       "ok": gv[0] == 0 and gv[1]},
                           "warmup": a.warmup, "data": "stub", "config": {"workload": "launcher self-test (no device work)",
                                                                           "gather": mode, "gather_bytes_per_step": r.gather_bytes_per_step()},
                           "gathered_counts": counts}), flush=True)
@@ -633,6 +900,13 @@ def main():
                          "workload geometry) instead of the synthetic stream")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency block")
     ap.add_argument("--latency-calls", type=int, default=200)
+    ap.add_argument("--latency-tail-calls", type=int, default=5000,
+                    help="calls behind the p50 / p99 / max of orbfe_track_frame and orbfe_track_reference_keyframe, alone and beside a "
+                         "mapping thread on its own handle (0 = skip)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="length of the second timed region (`sustained`: per-step p50 / p99 / max, measured clock); 0 = skip")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of 8 frames of the last timed step (`verified`) and the gather check")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--split", type=int, default=1,
                     help="extract the batch as this many sub-batches, each on its own handle and HIP stream, staggered by the order of "
@@ -808,6 +1082,28 @@ def main():
     dt, stage_ms, ncalls = timed_run(a.steps, a.warmup)
     ex.device_status()  # device-side guard flags of the last chain (raises if any is set); outside the timed region
 
+    # ---- the second timed region: the same loop for >= 5 s, per-step durations and the clock (the headline above is untouched) ----
+    sustained = None
+    if a.sustained_seconds > 0:
+        sustained = sustained_run(runner, ex, dev, dist, frames_total, a.sustained_seconds, dt / a.steps, rank, world)
+        ex.device_status()
+    # ---- the line checks itself: 8 frames of the last step that ran against the oracle; the gathered bytes against the packed ones ----
+    verified, gather_verified, all_ok = None, None, True
+    if not a.no_verify:
+        torch.cuda.synchronize(dev)
+        verified = verify_last_step(runner, frames_sets, state, B, cap, M, cfg)
+        ok = verified["kp_desc_equal"] and verified.get("match_equal", True)
+        gv = runner.verify_gather()
+        if gv is not None:
+            gather_verified = {"mismatching_slots_all_ranks": gv[0], "identical_on_all_ranks": gv[1], "ok": gv[0] == 0 and gv[1]}
+            ok = ok and gather_verified["ok"]
+        if dist is not None:  # every rank checks its own frames; one failing rank fails the job
+            t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            verified["ranks_failing"] = int(t[0].item())
+            ok = verified["ranks_failing"] == 0
+        all_ok = ok
+
     b_last = runner.bufs[0]
     n_kp_mean = float(b_last["n"][:B].float().mean().item())
     n_match_mean = float(b_last["nmatch"][:B].float().mean().item()) if M else None
@@ -825,16 +1121,24 @@ def main():
             M, GRID[0], GRID[1], MATCH_TH, MATCH_NN)
         prof = profile_for(dom, a.workload, B)
         issue = None
+        clk_hz = sustained["sclk_mhz"]["mean"] * 1e6 if sustained and sustained["sclk_mhz"]["mean"] else CLK_HZ
         if prof and prof.get("valu_per_wave") and prof.get("waves_per_launch"):
             wi = prof["waves_per_launch"] * prof["valu_per_wave"]
+            cyc_w = prof.get("valu_cycles_per_instruction_weighted")  # tools/isa_mix.py: emitted ISA x profiles/r03_valu_rate.txt
             issue = {"valu_per_wave": prof["valu_per_wave"], "salu_per_wave": prof.get("salu_per_wave"),
                      "lds_per_wave": prof.get("lds_per_wave"), "waves": prof["waves_per_launch"],
-                     # waves x valu / (1024 SIMDs x clk / 2 x t): the guide's 2-cycle wave64 VALU rate ...
-                     "issue_frac": wi / (SIMDS * CLK_HZ / 2.0 * dom_ms * 1e-3),
-                     # ... and against the rate tools/valu_rate.hip measures for packed / 32-bit min-max instructions (4 cycles per
-                     # wave64 instruction per SIMD; two thirds of this kernel's instructions are of the 2.3-cycle group:
-                     # profiles/r03_valu_rate.txt)
-                     "issue_frac_at_measured_4_cycles": wi / (SIMDS * CLK_HZ / 4.0 * dom_ms * 1e-3)}
+                     "clock_mhz": clk_hz / 1e6,
+                     "clock_source": "measured in this run (sustained.sclk_mhz.mean)" if clk_hz != CLK_HZ else "2400 MHz assumed (no probe)",
+                     # waves x valu / (1024 SIMDs x clk / 2 x t): the guide's 2-cycle wave64 VALU rate, the floor of the issue time ...
+                     "issue_frac": wi / (SIMDS * clk_hz / 2.0 * dom_ms * 1e-3),
+                     # ... and with every opcode of the kernel's emitted ISA priced at the rate tools/valu_rate.hip measures for its
+                     # group (2.1-2.6 cycles for the 16-bit min/max/add/sub and the 32-bit add/and/or/xor forms, 4.1-4.5 for packed,
+                     # dot, permute and 32-bit min/max): the share of the kernel's duration its vector instructions need to issue
+                     "valu_cycles_per_instruction_weighted": cyc_w,
+                     "issue_frac_weighted": wi * cyc_w / (SIMDS * clk_hz * dom_ms * 1e-3) if cyc_w else None,
+                     # counter-measured: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the committed profile
+                     "valu_busy": prof.get("valu_busy"),
+                     "profile_clock_mhz": prof.get("effective_clock_mhz")}
         out = {
             "metric": "frames/sec ORB %s, %dx%d %d-level %d-feat; bit-exact kp/desc" % (
                 "extract+match" if M else "extract", W, H, cfg[3], cfg[0]),
@@ -875,13 +1179,22 @@ def main():
                          "issue": issue,
                          "limiter": "VALU issue, with the LDS byte gathers of the corner-score stage as the second limit: packed-16, dot, "
                                     "permute and 32-bit min/max instructions cost ~4.2 cycles per wave64 instruction per SIMD, the 16-bit "
-                                    "min/max/sub and add/and/or/xor forms the FAST stages run on ~2.3 (profiles/r03_valu_rate.txt); 128 extra "
-                                    "packed instructions per wave cost 81 % of their saturated price (profiles/r03_ab_experiments.json)",
+                                    "min/max/sub and add/and/or/xor forms the FAST stages run on ~2.3 (profiles/r03_valu_rate.txt): "
+                                    "`issue.issue_frac_weighted` of the kernel's time is vector issue, `issue.valu_busy` is the counter's "
+                                    "reading of the same; 128 extra packed instructions per wave cost 81 % of their saturated price "
+                                    "(profiles/r03_ab_experiments.json)",
                          "input_set_bytes": int(n_sets * B * W * H),
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": dom_bytes,
                          "extract_pipeline_achieved_GBs": b_frame * B / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
                          "stage_ms_per_step": stage_avg},
         }
+        if sustained is not None:
+            out["sustained"] = sustained
+            out["sustained"]["headline_over_sustained"] = out["value"] / sustained["value"]
+        if verified is not None:
+            out["verified"] = verified
+        if gather_verified is not None:
+            out["gather_verified"] = gather_verified
         if emu:
             out["emulate_world"] = {"world": emu, "frames_per_step_total": C4_TOTAL_FRAMES,
                                     "predicted_value_at_world": C4_TOTAL_FRAMES * a.steps / dt,
@@ -932,7 +1245,7 @@ def main():
             out["texture_sweep"] = sweep
         if not a.no_latency and world == 1 and not emu:
             try:
-                out["latency"] = latency_block(cfg, local_rank, frames_sets[0], a.latency_calls)
+                out["latency"] = latency_block(cfg, local_rank, frames_sets[0], a.latency_calls, a.latency_tail_calls)
             except orbfe.OrbfeError as e:
                 out["latency"] = {"error": str(e)}
         if not a.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
@@ -947,9 +1260,14 @@ def main():
                                                                     a.cpu_seconds / 2, bool(M), orbfe.MP_DTYPE, a.cpu_threads)
                 out["cpu_baseline"]["all_cores"] = {"value": fps_all, "unit": "frames/s", "cores": used,
                                                     "sample": "%d frames over %d host threads, %.1f s wall" % (n_all, used, wall)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if not all_ok:
+        if rank == 0:
+            sys.stderr.write("bench.py: the timed path's results differ from the oracle / the gathered bytes from the packed ones: %s %s\n" % (
+                json.dumps(verified), json.dumps(gather_verified)))
+        sys.exit(4)
 
 
 if __name__ == "__main__":

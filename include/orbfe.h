@@ -432,7 +432,12 @@ typedef struct orbfe_map orbfe_map;
  * frame names its points by id (4 bytes each) instead of shipping 64 bytes per point per frame across PCIe.
  * orbfe_map_update (HOST pointers) writes entries ids[0..n) -- new points, and points whose position / descriptor /
  * observation count changed; it is ordered behind everything submitted before it and returns when the table is updated.
- * The `skip` member of the records is ignored (it is per frame: see orbfe_stream_submit_track). */
+ * The `skip` member of the records is ignored (it is per frame: see orbfe_stream_submit_track).
+ * Lifetime: orbfe_map_destroy waits for the handle's stream, drops the graphs of orbfe_track_frame_map and detaches the map
+ * from every ring it was given to (orbfe_stream_enable_track): that ring refuses later orbfe_stream_submit_track calls with
+ * ORBFE_ERR_INVALID_ARG (collect what is in flight BEFORE destroying the map).  orbfe_destroy releases the device memory of the
+ * maps and rings created from the handle; destroying them afterwards is safe and only frees the shell, any other call on them
+ * returns ORBFE_ERR_INVALID_ARG. */
 int orbfe_map_create(orbfe_handle *h, int capacity, orbfe_map **out);
 void orbfe_map_destroy(orbfe_map *m);
 int orbfe_map_update(orbfe_handle *h, orbfe_map *m, int n, const int *ids, const orbfe_world_point *points,
@@ -440,7 +445,8 @@ int orbfe_map_update(orbfe_handle *h, orbfe_map *m, int n, const int *ids, const
 
 /* Gives the ring what it needs to run the whole per-frame chain of orbfe_track_frame per slot: extraction, isInFrustum
  * of the frame's local map points against the frame's own pose, SearchByProjection -- H2D || extract + project + match ||
- * D2H.  max_points = the largest n_points a submission will carry.  Call once, before the first submission. */
+ * D2H.  max_points = the largest n_points a submission will carry.  Call once, before the first submission (a call that
+ * fails with ORBFE_ERR_OUT_OF_MEMORY leaves the ring as it was and may be repeated). */
 /* orbfe_track_frame with the local map points named by id out of the resident map (ids as orbfe_stream_submit_track:
  * id >= 0, ~id = skipped for this frame, outside the map = no point): 8 KB instead of 128 KB go up per frame at 2000
  * points.  mp_out / proj_xr_out / match_out index the id list.  Same results as orbfe_track_frame on the same points. */
@@ -470,7 +476,8 @@ typedef struct orbfe_keyframe orbfe_keyframe;
 /* Uploads what the key-frame matchers read from a KeyFrame and what never changes after its construction
  * (src/KeyFrame.cc:33-80): mvKeysUn (n keypoints), mDescriptors (n x 32), mFeatVec as node_id[i] = the
  * DBoW2::FeatureVector key of feature i (the vocabulary node `levelsup` levels above its word, src/Frame.cc:483-495;
- * -1 = the feature is in no node), stereo[i] != 0 iff mvuRight[i] >= 0 (NULL == monocular), mvScaleFactors.
+ * -1 = the feature is in no node: DBoW2 adds a feature to the FeatureVector only when its word's weight is > 0,
+ * TemplatedVocabulary.h:1168-1172, so features on stopped words get -1), stereo[i] != 0 iff mvuRight[i] >= 0 (NULL == monocular), mvScaleFactors.
  * The features of a node are walked in ascending feature index, the order DBoW2 stores them in
  * (Thirdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:1157-1170).  HOST pointers; one upload, then the key frame stays
  * on the device until orbfe_keyframe_destroy.  Keypoint octaves must lie in [0, n_levels). */
@@ -640,8 +647,10 @@ int orbfe_bow_transform(orbfe_handle *h, orbfe_vocab *v, const uint8_t *desc, in
  * as of this call (:182-187), orbfe_keyframe_size(kf) entries.  match_out[i] (capacity orbfe_max_keypoints()) = the
  * key-frame feature whose map point is written to vpMapPointMatches[i], or -1; n_matches = the return value.
  * The frame's descriptors never leave the device between extraction, descent and matching; nothing is decided on the
- * host in between.  Results are byte-identical to orbfe_extract -> orbfe_bow_transform -> orbfe_match_bow with the
- * FeatureVectors of both sides.  HOST pointers; gray may be pinned (read in place) or pageable. */
+ * host in between.  A frame feature whose word has weight 0 (a stopped word) is in no node of mFeatVec
+ * (TemplatedVocabulary.h:1168-1172,1196-1200) and takes no part in the matching, although its word_id_out / node_id_out /
+ * weight_out (== 0) are still returned.  Results are byte-identical to orbfe_extract -> orbfe_bow_transform ->
+ * orbfe_match_bow with the FeatureVectors of both sides (features with weight > 0 only).  HOST pointers; gray may be pinned (read in place) or pageable. */
 int orbfe_track_reference_keyframe(orbfe_handle *h, const uint8_t *gray, int pitch, const orbfe_vocab *vocab, int levelsup,
                                    const orbfe_keyframe *kf, const uint8_t *kf_has_mp, float nn_ratio,
                                    int check_orientation, orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out,
@@ -661,8 +670,14 @@ const char *orbfe_status_string(int status);
  * library itself never uses the NULL stream. */
 int orbfe_set_graph_capture(orbfe_handle *h, int enable);
 /* diagnostics: graphs this handle has captured so far, and captures that failed (e.g. invalidated by another thread's NULL-stream
- * call: the affected call ran on plain launches, its result is unaffected; after 8 failures a handle stops capturing) */
+ * call: the affected call ran on plain launches, its result is unaffected; after 8 failures IN A ROW a handle stops capturing
+ * until orbfe_set_graph_capture(h, 1)) */
 int orbfe_debug_graph_stats(orbfe_handle *h, int *captured, int *failed);
+/* diagnostics (bench.py's `sustained.sclk_mhz`): one wave on `stream` (NULL == the handle's stream; asynchronous) stamps the shader-cycle
+ * counter and the constant 100 MHz counter, sleeps for spin_us microseconds and stamps again: d_out[0] = shader cycles, d_out[1] =
+ * 100 MHz ticks that went by (DEVICE pointer to two 64-bit words), i.e. the clock the chip held meanwhile is d_out[0] / d_out[1] x
+ * 100 MHz.  Launched on a stream of its own beside a running workload it reads the clock THAT workload runs at. */
+int orbfe_debug_clock_probe(orbfe_handle *h, int spin_us, unsigned long long *d_out, void *stream);
 /* message of the last failing HIP call on this handle ("" if none) */
 const char *orbfe_last_error(const orbfe_handle *h);
 /* library / build identification, e.g. "orbfe 0.1 gfx950" */

@@ -236,7 +236,9 @@ __global__ __launch_bounds__(64) void bow_track_kernel(BowTrackArgs A)
     const BowKfRef R = *A.ref;
     if ((int)blockIdx.x >= R.G) return;
     const int nF = min(*A.nF, A.cap);
-    for (int i = lane; i < nF; i += 64) sNode[i] = A.fBow[2 * i + 1];
+    // stopped words (weight 0) never enter the FeatureVector (TemplatedVocabulary.h:1168-1172, 1196-1200): such a feature is in
+    // no node and SearchByBoW cannot match it; -1 equals no key-frame node (keyframe_create keeps node >= 0 only)
+    for (int i = lane; i < nF; i += 64) sNode[i] = A.weight[A.fLeaf[i]] > 0.0 ? A.fBow[2 * i + 1] : -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     constexpr unsigned kNone = 0xffffffffu;

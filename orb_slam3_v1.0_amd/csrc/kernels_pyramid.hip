@@ -446,17 +446,18 @@ __device__ __forceinline__ uint32_t chain_px(const ChainCtx& c, int x, int y)
     return v >> 22;
 }
 
-// thread -> one pixel of one of the `depth` output levels (adjacent lanes store adjacent bytes); grid.y covers the pixels of
-// all of them.  One pixel per thread keeps the dependent chain of a thread at `depth` rounds of loads.
+// thread -> one pixel of one of the `depth` output levels (adjacent lanes store adjacent bytes); grid.x covers the pixels of
+// all of them (grid.x is the dimension without the 65535 limit: two levels of a 4095 x 4095 frame are 77 k blocks), grid.y
+// the frames.  One pixel per thread keeps the dependent chain of a thread at `depth` rounds of loads.
 __global__ __launch_bounds__(256) void pyramid_chain_kernel(const PipelineDesc* __restrict__ P, int l0, int depth,
                                                             const uint8_t* __restrict__ gray0, size_t gray0FrameStride, int gray0Pitch,
                                                             uint8_t* __restrict__ ws, const uint32_t* __restrict__ tabs,
                                                             uint32_t* __restrict__ zero, int nZeroPerFrame)
 {
-    const int f = blockIdx.x;
+    const int f = blockIdx.y;
     // the first launch of a chain also clears the frame's per-level counters (FAST, two launches later at the earliest, is
     // their first user): one node less in the chain than a separate memset
-    if (zero && blockIdx.y == 0)
+    if (zero && blockIdx.x == 0)
         for (int i = threadIdx.x; i < nZeroPerFrame; i += 256) zero[(size_t)f * nZeroPerFrame + i] = 0;
     ChainCtx c;
     const LevelDesc& S = P->lv[l0];
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256) void pyramid_chain_kernel(const PipelineDesc* 
         c.h[k] = D.h;
         np[k] = k < depth ? D.w * D.h : 0;
     }
-    int idx = (int)blockIdx.y * 256 + (int)threadIdx.x;
+    int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
     int k = 0;
     if (idx >= np[0]) { idx -= np[0]; k = 1; if (idx >= np[1]) { idx -= np[1]; k = 2; if (idx >= np[2]) return; } }
     const LevelDesc& D = P->lv[l0 + 1 + k];
@@ -498,7 +499,7 @@ void launch_pyramid_chain(hipStream_t s, int frames, const PipelineDesc* dP, con
         const LevelDesc& D = hostP.lv[l0 + 1 + k];
         pixels += (long long)D.w * D.h;
     }
-    hipLaunchKernelGGL(pyramid_chain_kernel, dim3(frames, (unsigned)((pixels + 255) / 256)), dim3(256), 0, s, dP, l0, depth, gray0,
+    hipLaunchKernelGGL(pyramid_chain_kernel, dim3((unsigned)((pixels + 255) / 256), frames), dim3(256), 0, s, dP, l0, depth, gray0,
                        gray0FrameStride, gray0Pitch, ws, tabs, zero, nZeroPerFrame);
 }
 

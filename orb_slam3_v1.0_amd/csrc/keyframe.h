@@ -54,6 +54,8 @@ struct BowTrackArgs {
     const orbfe_keypoint* fKp;  // frame keypoints (orientation), descriptors, (word, node) of every feature, count
     const uint8_t* fDesc;
     const int* fBow;            // [cap][2]
+    const int* fLeaf;           // [cap] the leaf (word) every feature reached, and the vocabulary's node weights: a feature whose
+    const double* weight;       // word has weight 0 is in no node of mFeatVec (addFeature runs only for w > 0: TemplatedVocabulary.h:1168-1172)
     const int* nF;
     int cap;
     float nnRatio;

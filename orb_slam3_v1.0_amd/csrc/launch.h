@@ -40,4 +40,7 @@ void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const Pipeli
                          const uint32_t* lvlKp, orbfe_keypoint* kpOut, uint8_t* descOut, int* nOut,
                          int* perLevelOut, int* statusOut, const int* kpBase, int nLevels);
 
+// kernels_probe.hip: one wave writes {shader cycles, 100 MHz ticks} spent while `ticks` of the constant clock went by
+void launch_clock_probe(hipStream_t s, unsigned long long* dOut2, unsigned ticks);
+
 }  // namespace orbfe

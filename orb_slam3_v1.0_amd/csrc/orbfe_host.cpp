@@ -40,6 +40,9 @@ const char* kStageNames[ORBFE_NUM_STAGES] = {"pyramid_resize", "fast_nms_blur",
 
 }  // namespace
 
+struct orbfe_map;
+struct orbfe_stream;
+
 struct orbfe_handle {
     orbfe_params prm{};
     int device = 0;
@@ -87,7 +90,8 @@ struct orbfe_handle {
     // the whole host-API call (H2D, kernel chain, D2H) as a captured hipGraph per batch size (latency path)
     std::map<int, hipGraphExec_t> graphs;
     bool useGraph = true;
-    int graphCaptures = 0, captureFailures = 0;  // orbfe_debug_graph_stats
+    int graphCaptures = 0, captureFailures = 0;  // orbfe_debug_graph_stats (totals since create / the last orbfe_set_graph_capture(1))
+    int captureFailStreak = 0;                   // CONSECUTIVE failed captures: a successful one resets it
 
     hipStream_t stream = nullptr;
     bool timing = false;
@@ -138,6 +142,10 @@ struct orbfe_handle {
     std::vector<RefGraph> refGraphs;
     std::mutex mu;
     std::string err;
+    // objects that keep a pointer to this handle: orbfe_destroy releases their device memory and orphans them (h = null), so
+    // that destroying them afterwards -- a binding's finalisers run in any order -- only frees the empty shell
+    std::vector<orbfe_map*> maps;
+    std::vector<orbfe_stream*> rings;
 
     // Cross-stream ordering of the scratch the handle owns: an event recorded behind the last enqueue that used the
     // extraction scratch (pyramid, candidates, counters, level keypoints) / the matcher arena, and the stream it ran on.
@@ -209,11 +217,14 @@ void fill_resize_table(std::vector<uint32_t>& t, size_t off, int srcN, int dstN)
     for (size_t x = (size_t)dstN; x < align_up((size_t)dstN, 4); x++) t[off + x] = t[off + dstN - 1];
 }
 
+void orphan_children(orbfe_handle* h);  // defined behind orbfe_map / orbfe_stream
+
 void destroy_impl(orbfe_handle* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    orphan_children(h);
     for (auto& set : h->ev)
         for (auto& e : set)
             if (e) (void)hipEventDestroy(e);
@@ -667,7 +678,7 @@ static int extract_host_enqueue(orbfe_handle* h, int batch, int inPitch, hipStre
 // and although the stream is non-blocking (tools/probes/capture_invalidate.cpp): every later call on it returns
 // hipErrorStreamCaptureInvalidated.  With a throw-away stream such an encounter costs the call that was capturing its graph,
 // not the handle: the stream is destroyed, the call runs on plain launches, a later call captures again.  Only a handle
-// whose captures keep failing stops trying.  (The library itself makes no NULL-stream call: copy_sync / memset_sync.)
+// whose captures fail eight times IN A ROW stops trying (a success resets the count).  (The library itself makes no NULL-stream call: copy_sync / memset_sync.)
 struct CaptureStream {
     hipStream_t s = nullptr;
     bool capturing = false;
@@ -713,7 +724,14 @@ struct CaptureStream {
 static void graph_capture_failed(orbfe_handle* h)
 {
     (void)hipGetLastError();
-    if (++h->captureFailures >= 8) h->useGraph = false;
+    h->captureFailures++;
+    if (++h->captureFailStreak >= 8) h->useGraph = false;  // eight in a row: this handle's captures keep failing
+}
+
+static void graph_capture_succeeded(orbfe_handle* h)
+{
+    h->graphCaptures++;
+    h->captureFailStreak = 0;  // an occasional foreign NULL-stream call over a long run never adds up to the limit
 }
 
 // extract_host_enqueue, replayed from a hipGraph when possible: every pointer behind the upload is owned by the
@@ -750,7 +768,7 @@ static int extract_enqueue_replay(orbfe_handle* h, int batch, int inPitch, hipSt
                     graph_capture_failed(h);
                     viaGraph = false;
                 } else {
-                    h->graphCaptures++;
+                    graph_capture_succeeded(h);
                 }
             }
         }
@@ -1066,7 +1084,7 @@ static int track_frame_impl(orbfe_handle* h, const uint8_t* gray, int pitch, con
                 graph_capture_failed(h);  // plain launches for this call
                 viaGraph = false;
             } else {
-                h->graphCaptures++;
+                graph_capture_succeeded(h);
                 if (h->trackGraphs.size() >= 64) track_drop_graphs(h);  // a caller cycling through parameters: bounded cache
                 h->trackGraphs.push_back({key, exec});
             }
@@ -1240,9 +1258,11 @@ struct orbfe_stream {
 
 extern "C" {
 
-void orbfe_stream_destroy(orbfe_stream* st)
+}  // extern "C"
+
+// everything a ring owns except the struct itself; the handle is still alive
+static void stream_release(orbfe_stream* st)
 {
-    if (!st) return;
     orbfe_handle* h = st->h;
     (void)hipSetDevice(h->device);
     if (st->sIn) (void)hipStreamSynchronize(st->sIn);
@@ -1261,9 +1281,29 @@ void orbfe_stream_destroy(orbfe_stream* st)
         for (hipEvent_t e : {sl.evIn, sl.evDone, sl.evOut})
             if (e) (void)hipEventDestroy(e);
     }
+    st->slots.clear();
     if (st->sIn) (void)hipStreamDestroy(st->sIn);
     if (st->sOut) (void)hipStreamDestroy(st->sOut);
+    st->sIn = st->sOut = nullptr;
     delete st->pool;
+    st->pool = nullptr;
+    st->map = nullptr;
+}
+
+extern "C" {
+
+void orbfe_stream_destroy(orbfe_stream* st)
+{
+    if (!st) return;
+    if (st->h) {  // (null: the handle went first and released the ring's memory, orphan_children)
+        orbfe_handle* h = st->h;
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            for (size_t i = 0; i < h->rings.size(); i++)
+                if (h->rings[i] == st) h->rings.erase(h->rings.begin() + (long)i--);
+        }
+        stream_release(st);
+    }
     delete st;
 }
 
@@ -1303,11 +1343,13 @@ int orbfe_stream_create(orbfe_handle* h, int slots, int slot_frames, orbfe_strea
     if (!ok) {
         (void)hipGetLastError();
         h->err = "orbfe_stream_create: allocation failed";
-        orbfe_stream_destroy(st);
+        stream_release(st);  // (not yet registered with the handle; h->mu is held)
+        delete st;
         return ORBFE_ERR_OUT_OF_MEMORY;
     }
     const unsigned hw = std::thread::hardware_concurrency();
     st->pool = new RowCopyPool((int)std::min<unsigned>(7u, hw > 2 ? hw / 2 : 1));
+    h->rings.push_back(st);
     *out = st;
     return ORBFE_OK;
 }
@@ -1321,7 +1363,7 @@ int orbfe_stream_in_flight(const orbfe_stream* st)
 static int stream_submit_impl(orbfe_stream* st, const uint8_t* const* grays, int pitch, int n, const orbfe_track_params* tp,
                               const orbfe_frustum* frusta, int nPoints, const int* ids)
 {
-    if (!st || !grays || n < 1 || n > st->slotFrames) return ORBFE_ERR_INVALID_ARG;
+    if (!st || !st->h || !grays || n < 1 || n > st->slotFrames) return ORBFE_ERR_INVALID_ARG;
     orbfe_handle* h = st->h;
     if (pitch < h->prm.image_width) return ORBFE_ERR_INVALID_ARG;
     const bool track = tp != nullptr;
@@ -1479,8 +1521,8 @@ int orbfe_stream_submit_track(orbfe_stream* st, const uint8_t* const* grays, int
 
 int orbfe_stream_enable_track(orbfe_stream* st, orbfe_map* map, int max_points)
 {
-    if (!st || !map || map->h != st->h || max_points < 1 || max_points > (1 << 24)) return ORBFE_ERR_INVALID_ARG;
-    if (st->map || st->submitted.load() != st->collected.load()) return ORBFE_ERR_INVALID_ARG;  // once, on an idle ring
+    if (!st || !st->h || !map || map->h != st->h || max_points < 1 || max_points > (1 << 24)) return ORBFE_ERR_INVALID_ARG;
+    if (st->map || st->slots[0].dTrkIn || st->submitted.load() != st->collected.load()) return ORBFE_ERR_INVALID_ARG;  // once, on an idle ring
     orbfe_handle* h = st->h;
     if (h->P.kpCapFrame >= (1 << 20)) return ORBFE_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1499,8 +1541,17 @@ int orbfe_stream_enable_track(orbfe_stream* st, orbfe_map* map, int max_points)
              hipHostMalloc(&sl.hTrkOut, st->trkOutBytes) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
+        // give back what was allocated: the ring stays usable for plain submissions, and a retry starts from empty slots
+        for (auto& sl : st->slots) {
+            if (sl.hTrkIn) (void)hipHostFree(sl.hTrkIn);
+            if (sl.dTrkIn) (void)hipFree(sl.dTrkIn);
+            if (sl.dTrkWork) (void)hipFree(sl.dTrkWork);
+            if (sl.dTrkOut) (void)hipFree(sl.dTrkOut);
+            if (sl.hTrkOut) (void)hipHostFree(sl.hTrkOut);
+            sl.hTrkIn = sl.dTrkIn = sl.dTrkWork = sl.dTrkOut = sl.hTrkOut = nullptr;
+        }
         h->err = "orbfe_stream_enable_track: allocation failed";
-        return ORBFE_ERR_OUT_OF_MEMORY;  // (what was allocated is released by orbfe_stream_destroy)
+        return ORBFE_ERR_OUT_OF_MEMORY;
     }
     st->map = map;
     st->maxPoints = max_points;
@@ -1510,7 +1561,7 @@ int orbfe_stream_enable_track(orbfe_stream* st, orbfe_map* map, int max_points)
 // waits for the oldest submission and checks its guard flags; *slot_out stays in flight until the caller bumps `collected`
 static int stream_wait_oldest(orbfe_stream* st, StreamSlot** slot_out)
 {
-    if (!st) return ORBFE_ERR_INVALID_ARG;
+    if (!st || !st->h) return ORBFE_ERR_INVALID_ARG;
     const unsigned long long seq = st->collected.load(std::memory_order_relaxed);
     if (st->submitted.load(std::memory_order_acquire) == seq) return ORBFE_ERR_INVALID_ARG;
     orbfe_handle* h = st->h;
@@ -1638,19 +1689,38 @@ int orbfe_map_create(orbfe_handle* h, int capacity, orbfe_map** out)
             return ORBFE_ERR_HIP;
         }
     (void)memset_sync(m->dDesc, 0, (size_t)capacity * ORBFE_DESC_BYTES, h->stream);
+    h->maps.push_back(m);
     *out = m;
     return ORBFE_OK;
+}
+
+// the map's device memory and every reference to it; the caller holds m->h->mu (or is the handle's destruction)
+static void map_release(orbfe_map* m)
+{
+    orbfe_handle* h = m->h;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    track_drop_graphs(h);  // graphs of orbfe_track_frame_map hold this map's addresses
+    for (orbfe_stream* st : h->rings)
+        if (st->map == m) {  // a ring that was given this map: its later track submissions are refused, not served from freed memory
+            st->map = nullptr;
+            st->maxPoints = 0;
+        }
+    if (m->dPts) (void)hipFree(m->dPts);
+    if (m->dDesc) (void)hipFree(m->dDesc);
+    m->dPts = nullptr;
+    m->dDesc = nullptr;
 }
 
 void orbfe_map_destroy(orbfe_map* m)
 {
     if (!m) return;
-    std::lock_guard<std::mutex> lk(m->h->mu);
-    (void)hipSetDevice(m->h->device);
-    (void)hipStreamSynchronize(m->h->stream);
-    track_drop_graphs(m->h);  // graphs of orbfe_track_frame_map hold this map's addresses
-    if (m->dPts) (void)hipFree(m->dPts);
-    if (m->dDesc) (void)hipFree(m->dDesc);
+    if (m->h) {  // (null: the handle went first, orphan_children)
+        std::lock_guard<std::mutex> lk(m->h->mu);
+        for (size_t i = 0; i < m->h->maps.size(); i++)
+            if (m->h->maps[i] == m) m->h->maps.erase(m->h->maps.begin() + (long)i--);
+        map_release(m);
+    }
     delete m;
 }
 
@@ -1693,6 +1763,24 @@ int orbfe_map_update(orbfe_handle* h, orbfe_map* m, int n, const int* ids, const
 }
 
 }  // extern "C"
+
+namespace {
+// orbfe_destroy with maps / rings still alive: release their memory now (the device context of the handle is still
+// current) and cut the back pointers; their own destroy calls then only delete the shells
+void orphan_children(orbfe_handle* h)
+{
+    for (orbfe_stream* st : h->rings) {
+        stream_release(st);
+        st->h = nullptr;
+    }
+    h->rings.clear();
+    for (orbfe_map* m : h->maps) {
+        map_release(m);
+        m->h = nullptr;
+    }
+    h->maps.clear();
+}
+}  // namespace
 
 extern "C" {
 
@@ -1752,7 +1840,17 @@ int orbfe_set_graph_capture(orbfe_handle* h, int enable)
     if (!h) return ORBFE_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
     h->useGraph = enable != 0;
-    if (enable) h->captureFailures = 0;
+    if (enable) h->captureFailures = h->captureFailStreak = 0;
+    return ORBFE_OK;
+}
+
+int orbfe_debug_clock_probe(orbfe_handle* h, int spin_us, unsigned long long* d_out, void* stream)
+{
+    if (!h || !d_out || spin_us < 1 || spin_us > 100000) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_clock_probe(stream ? static_cast<hipStream_t>(stream) : h->stream, d_out, (unsigned)spin_us * 100u);
+    HIPCHK(h, hipGetLastError());
     return ORBFE_OK;
 }
 
@@ -2469,6 +2567,8 @@ int ref_enqueue(orbfe_handle* h, const RefLayout& L, int inPitch, const orbfe::V
         A.fKp = dKp;
         A.fDesc = h->dRefOut + L.oDesc;
         A.fBow = dBow;
+        A.fLeaf = reinterpret_cast<const int*>(h->dRefOut + L.oLeaf);
+        A.weight = v->dWeight;
         A.nF = dHead;
         A.cap = cap;
         A.nnRatio = nnRatio;
@@ -2563,7 +2663,7 @@ extern "C" int orbfe_track_reference_keyframe(orbfe_handle* h, const uint8_t* gr
                 graph_capture_failed(h);  // plain launches for this call
                 viaGraph = false;
             } else {
-                h->graphCaptures++;
+                graph_capture_succeeded(h);
                 if (h->refGraphs.size() >= 16) ref_drop_graphs(h);  // vocabularies / parameters cycling: bounded cache
                 h->refGraphs.push_back({key, exec});
             }

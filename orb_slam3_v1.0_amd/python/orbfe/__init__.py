@@ -119,6 +119,7 @@ SYMBOLS = [
     "orbfe_keyframe_create", "orbfe_keyframe_destroy", "orbfe_keyframe_size", "orbfe_match_triangulation_batch",
     "orbfe_triangulation_select", "orbfe_map_create", "orbfe_map_destroy", "orbfe_map_update", "orbfe_stream_enable_track",
     "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map", "orbfe_track_reference_keyframe", "orbfe_debug_graph_stats", "orbfe_set_graph_capture",
+    "orbfe_debug_clock_probe",
 ]
 
 _lib = None
@@ -166,6 +167,7 @@ def lib():
     L.orbfe_get_device_status.argtypes = [vp, vp]
     L.orbfe_debug_graph_stats.argtypes = [vp, vp, vp]
     L.orbfe_set_graph_capture.argtypes = [vp, ci]
+    L.orbfe_debug_clock_probe.argtypes = [vp, ci, vp, vp]
     L.orbfe_stream_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
     L.orbfe_stream_destroy.argtypes = [vp]
     L.orbfe_stream_destroy.restype = None
@@ -365,6 +367,10 @@ class ORBextractor:
         a, b = C.c_int(), C.c_int()
         self._chk(self.L.orbfe_debug_graph_stats(self.h, C.byref(a), C.byref(b)), "orbfe_debug_graph_stats")
         return a.value, b.value
+
+    def clock_probe(self, d_out_ptr, spin_us=20, stream=None):
+        """orbfe_debug_clock_probe: asynchronous; d_out_ptr -> two device uint64 {shader cycles, 100 MHz ticks}"""
+        self._chk(self.L.orbfe_debug_clock_probe(self.h, int(spin_us), d_out_ptr, stream), "orbfe_debug_clock_probe")
 
     def set_stage_timing(self, on):
         self._chk(self.L.orbfe_set_stage_timing(self.h, int(on)), "set_stage_timing")

@@ -99,6 +99,8 @@ int main(int argc, char** argv)
         std::vector<int> word((size_t)cap), node((size_t)cap), matchR((size_t)cap);
         std::vector<double> w((size_t)cap);
         rc |= orbfe_bow_transform(h, voc, desc.data(), n, levelsup, word.data(), node.data(), w.data());
+        for (int i = 0; i < n; i++)  // the key frame's mFeatVec: a feature on a stopped word (weight 0) is in no node
+            if (!(w[(size_t)i] > 0.0)) node[(size_t)i] = -1;
         std::vector<float> sf(8);
         {
             float s = 1.f;

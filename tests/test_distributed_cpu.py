@@ -122,6 +122,14 @@ def _runner_worker(rank, world, port, out_q):
     for _ in range(3):
         r.step()
     assert calls == [0, 1, 0]                       # the steps rotate through the frame sets
+    # bench.py --verify-gather semantics: this rank's slots of g_out / g_n hold what it packed, every rank holds the same bytes
+    assert r.verify_gather() == (0, True)
+    if rank == 1:                                   # a corrupted slot on one rank is seen by all of them
+        r.g_out[rank * Bpad, 0, 3] ^= 0x40
+    bad, same = r.verify_gather()
+    assert bad == 1 and same is False
+    if rank == 1:
+        r.g_out[rank * Bpad, 0, 3] ^= 0x40
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -186,6 +194,7 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert out["config"]["gather"] == "counts" and out["config"]["gather_bytes_per_step"] == 2 * 3 * 8
     # rank-major (keypoints, matches) per frame: rank r frame j -> (3 r + j + 1, r + j)
     assert out["gathered_counts"] == [[[1, 0], [2, 1], [3, 2]], [[4, 1], [5, 2], [6, 3]]]
+    assert out["gather_verified"] == {"mismatching_slots_all_ranks": 0, "identical_on_all_ranks": True, "ok": True}
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():

@@ -67,9 +67,10 @@ def test_track_latency_program_runs_and_agrees_with_the_oracle(built, tmp_path):
     # the chain against the reference key frame from C++: the frame's own features as the key frame, checked against the oracle
     mr = re.search(r"c_abi_latency_us track_reference_keyframe=([0-9.]+) keypoints=(\d+) ref_matches=(\d+) self=(\d+) rc=0", out)
     assert mr, out
-    _, node, _ = O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 4, desc, levelsup)
+    _, node, wt = O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 4, desc, levelsup)
+    node = np.where(wt > 0, node, -1)  # mFeatVec holds features whose word has weight > 0 only (TemplatedVocabulary.h:1168-1172)
     kfOff, kfIdx = [0], []
-    for g in sorted(set(node.tolist())):
+    for g in sorted(set(node.tolist()) - {-1}):
         kfIdx += list(np.flatnonzero(node == g))
         kfOff.append(len(kfIdx))
     n_b, m_b = O.search_by_bow(kfOff, kfIdx, kfOff, kfIdx, desc, kp["angle"], np.ones(len(kp), np.uint8), desc, kp["angle"], 0.75, True)

@@ -35,7 +35,8 @@ def oracle_chain(eo, t, levelsup, img, kf, has, nn, check):
     word, node, weight = O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], t["L"], desc, levelsup)
     if len(kp) == 0 or len(kf["kp"]) == 0:
         return dict(kp=kp, desc=desc, per=per, word=word, node=node, weight=weight, n=0, match=np.full(len(kp), -1, np.int32))
-    kfOff, kfIdx, fOff, fIdx = csr(kf["node"], node)
+    # a feature enters mFeatVec only when its word's weight is > 0 (TemplatedVocabulary.h:1168-1172,1196-1200)
+    kfOff, kfIdx, fOff, fIdx = csr(kf["node"], np.where(weight > 0, node, -1))
     n, match = O.search_by_bow(kfOff, kfIdx, fOff, fIdx, kf["desc"], kf["kp"]["angle"], has, desc, kp["angle"], nn, check)
     return dict(kp=kp, desc=desc, per=per, word=word, node=node, weight=weight, n=n, match=match)
 
@@ -54,8 +55,9 @@ def same(got, ref, what):
 
 def make_kf(eo, t, levelsup, img):
     kp, desc, _ = eo.extract(img)
-    _, node, _ = O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], t["L"], desc, levelsup)
-    return dict(kp=kp, desc=desc, node=node.astype(np.int32))
+    _, node, weight = O.vocab_transform(t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], t["L"], desc, levelsup)
+    # the key frame's mFeatVec: features on stopped words (weight 0) are in no node (-1 for orbfe_keyframe_create)
+    return dict(kp=kp, desc=desc, node=np.where(weight > 0, node, -1).astype(np.int32))
 
 
 @pytest.mark.parametrize("k,L,levelsup", [(10, 5, 3), (10, 6, 4), (6, 4, 1), (6, 4, 4)])
@@ -97,6 +99,35 @@ def test_chain_equals_oracle_on_a_stream(built, k, L, levelsup):
     voc.close()
 
 
+def test_stopped_words_take_no_part_in_the_matching(built):
+    """DBoW2 adds a feature to the FeatureVector only when its word's weight is > 0 (TemplatedVocabulary.h:1168-1172,
+    1196-1200): with half of the words stopped, the features on them must stay unmatched -- on the frame side (decided on
+    the device from the leaf's weight) and on the key-frame side (node -1) -- although they would match if they took part."""
+    import orbfe
+    from orbfe import synth
+    W, H = C1[6], C1[7]
+    eo = O.Extractor(*C1)
+    ex = orbfe.ORBextractor(*C1)
+    t = vs.spread_first_level(vs.make_tree(10, 5, seed=41, early_leaf_p=0.03, dup_p=0.05, stop_p=0.5), 42)
+    voc = orbfe.ORBVocabulary(ex, t["childOff"], t["childIdx"], t["nodeDesc"], t["wordId"], t["weight"], 5)
+    trk = orbfe.FrameTracker(ex, 64, 48, 0.0, 0.0, float(W), float(H))
+    img = synth.frame(W, H, 640)
+    kf = make_kf(eo, t, 3, img)  # the frame's own image as the key frame: every feature would find itself
+    res = orbfe.KeyFrame(ex, kf["kp"].view(orbfe.KP_DTYPE), kf["desc"], kf["node"], eo.scaleFactors)
+    has = np.ones(len(kf["kp"]), np.uint8)
+    got = trk.TrackReferenceKeyFrame(img, voc, 3, res, has, 0.75, False)
+    ref = oracle_chain(eo, t, 3, img, kf, has, 0.75, False)
+    same(got, ref, "half of the words stopped")
+    stopped = ref["weight"] <= 0
+    assert 0.3 < stopped.mean() < 0.7 and (got["match"][stopped] == -1).all() and got["nmatches"] > 200
+    # the unfiltered walk (every feature in its node, weight ignored) matches stopped features too: the filter matters here
+    kfAll = dict(kf, node=ref["node"].astype(np.int32))
+    n_all, m_all = O.search_by_bow(*csr(kfAll["node"], ref["node"]), kf["desc"], kf["kp"]["angle"], has, ref["desc"], ref["kp"]["angle"],
+                                   0.75, False)
+    assert (m_all[stopped] >= 0).sum() > 100 and n_all > got["nmatches"]
+    voc.close()
+
+
 def test_chain_equals_the_three_calls_and_the_plain_launch_path(built):
     """== orbfe_extract + orbfe_bow_transform + orbfe_match_bow on the same handle, interleaved with them, and == its own
     plain-launch path (stage timing on)."""
@@ -117,7 +148,7 @@ def test_chain_equals_the_three_calls_and_the_plain_launch_path(built):
         img = synth.frame(W, H, 500 + i)
         kp0, desc0 = ex.extractFeatures(img)
         w0, n0, wt0 = voc.transform(desc0, 3)
-        kfOff, kfIdx, fOff, fIdx = csr(kf["node"], n0)
+        kfOff, kfIdx, fOff, fIdx = csr(kf["node"], np.where(wt0 > 0, n0, -1))  # mFeatVec holds features with weight > 0 only
         n3, match3 = m.SearchByBoW(kfOff, kfIdx, fOff, fIdx, kf["desc"], kf["kp"]["angle"], has, desc0, kp0["angle"], 0.75, True)
         got = trk.TrackReferenceKeyFrame(img, voc, 3, res, has, 0.75, True)
         assert got["kp"].tobytes() == kp0.tobytes() and np.array_equal(got["desc"], desc0)
@@ -177,7 +208,7 @@ def test_edge_cases(built):
     same(trk.TrackReferenceKeyFrame(img, voc, 2, res, has), oracle_chain(eo, t, 2, img, kf, has, 0.75, True), "small one again")
     # levelsup >= L: nid level <= 0 -> every feature's node is the root
     kf0 = make_kf(eo, t, 4, synth.frame(W, H, 76))
-    assert (kf0["node"] == 0).all()
+    assert ((kf0["node"] == 0) | (kf0["node"] == -1)).all() and (kf0["node"] == 0).sum() > 100  # (-1: stopped words)
     res0 = orbfe.KeyFrame(ex, kf0["kp"].view(orbfe.KP_DTYPE), kf0["desc"], kf0["node"], eo.scaleFactors)
     same(trk.TrackReferenceKeyFrame(img, voc, 4, res0, has), oracle_chain(eo, t, 4, img, kf0, has, 0.75, True), "one node")
     # invalid arguments are refused

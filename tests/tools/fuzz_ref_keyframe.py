@@ -67,7 +67,11 @@ def one(rng, k):
         kkp, kdesc = kkp[perm].copy(), kdesc[perm].copy()
         flip = rng.random(len(kkp)) < 0.3
         kdesc[flip, int(rng.integers(0, 32))] ^= np.uint8(1 << int(rng.integers(0, 8)))
-    knode = tv(kdesc)[1].astype(np.int32) if len(kkp) else np.zeros(0, np.int32)
+    if len(kkp):  # the key frame's mFeatVec: features on stopped words (weight 0) are in no node (TemplatedVocabulary.h:1168-1172)
+        _, kn_, kw_ = tv(kdesc)
+        knode = np.where(kw_ > 0, kn_, -1).astype(np.int32)
+    else:
+        knode = np.zeros(0, np.int32)
     if len(knode) and rng.random() < 0.3:
         knode[rng.random(len(knode)) < 0.05] = -1  # features the key frame's FeatureVector does not hold
     has = (rng.random(len(kkp)) < float(rng.choice([0.3, 0.7, 1.0]))).astype(np.uint8)
@@ -85,7 +89,7 @@ def one(rng, k):
     if len(kp) == 0 or len(kkp) == 0:
         n_ref, m_ref = 0, np.full(len(kp), -1, np.int32)
     else:
-        n_ref, m_ref = O.search_by_bow(*csr(knode, node), kdesc, kkp["angle"], has, desc, kp["angle"], nn, check)
+        n_ref, m_ref = O.search_by_bow(*csr(knode, np.where(weight > 0, node, -1)), kdesc, kkp["angle"], has, desc, kp["angle"], nn, check)
     assert got["nmatches"] == n_ref and np.array_equal(got["match"], m_ref), what + ": %d vs %d matches" % (got["nmatches"], n_ref)
     voc.close()
     res.close()
