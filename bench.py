@@ -425,16 +425,27 @@ def _pct(v, q):
     return float(np.percentile(np.asarray(v, np.float64), q))
 
 
-def sustained_run(runner, ex, dev, dist, frames_total, seconds, est_step_s, rank, world):
+def sustained_run(runner, ex, dev, dist, frames_total, seconds, rank, world):
     """The same step loop as the headline region, for >= `seconds` of wall time: one HIP event behind every step (its
     duration = the distance to the previous step's event), and every ~1/64th of the run one clock probe
     (orbfe_debug_clock_probe, 20 us, one wave) on a stream of its own released by that step's event, so the probes are
     spread over the region and read the clock the extraction kernels run at.  Wall time between barriers, MAX over ranks, like
     the headline.  The reference's cadence is a continuous stream (mono_inertial_node.cpp:207), not a burst."""
-    n_steps = max(200, int(np.ceil(seconds * 1.04 / max(est_step_s, 1e-6))))
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
-    every = max(1, n_steps // 64)
-    probes = torch.zeros((n_steps // every + 4, 2), dtype=torch.int64, device=dev)
+    # the headline's few steps are a poor estimate of the step time: calibrate on 64 untimed steps (MAX over ranks, so that every
+    # rank derives the same step count -- the per-step collective needs that)
+    torch.cuda.synchronize(dev)
+    tc = time.perf_counter()
+    for _ in range(64):
+        runner.step()
+    torch.cuda.synchronize(dev)
+    est_step_s = max((time.perf_counter() - tc) / 64, 1e-6)
+    if dist is not None:
+        t = torch.tensor([est_step_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        est_step_s = float(t[0].item())
+    n_first = max(200, int(np.ceil(seconds * 1.04 / est_step_s)))
+    every = max(1, n_first // 64)
+    probes = torch.zeros((4096, 2), dtype=torch.int64, device=dev)
     s3 = torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)
     ex.clock_probe(probes[0].data_ptr(), 20, s3.cuda_stream)  # the clock of the idle chip, for comparison
@@ -443,14 +454,33 @@ def sustained_run(runner, ex, dev, dist, frames_total, seconds, est_step_s, rank
         dist.barrier()
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    evs = [torch.cuda.Event(enable_timing=True)]
     evs[0].record(runner.s2)
     k = 1
-    for i in range(n_steps):
-        runner.step(done_event=evs[i + 1])
-        if i % every == every // 2:
-            s3.wait_event(evs[i + 1])
-            ex.clock_probe(probes[k].data_ptr(), 20, s3.cuda_stream)
-            k += 1
+
+    def enqueue(count):
+        nonlocal k
+        for _ in range(count):
+            i = len(evs) - 1
+            evs.append(torch.cuda.Event(enable_timing=True))
+            runner.step(done_event=evs[-1])
+            if i % every == every // 2 and k < len(probes):
+                s3.wait_event(evs[-1])
+                ex.clock_probe(probes[k].data_ptr(), 20, s3.cuda_stream)
+                k += 1
+
+    enqueue(n_first)
+    # single process: look at the events 32 steps before the end of what is enqueued (the queue never drains) and top up until the
+    # region covers `seconds` (with several ranks the count is fixed by the calibration above: agreeing on a top-up would drain it)
+    for _ in range(64 if dist is None else 0):
+        j = max(1, len(evs) - 1 - 32)
+        evs[j].synchronize()
+        per_step = evs[0].elapsed_time(evs[j]) / j
+        more = int(np.ceil((seconds * 1e3 * 1.03 - per_step * (len(evs) - 1)) / max(per_step, 1e-3)))
+        if more <= 0 or len(evs) > 400000:
+            break
+        enqueue(max(more, 16))
+    n_steps = len(evs) - 1
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -1085,7 +1115,7 @@ def main():
     # ---- the second timed region: the same loop for >= 5 s, per-step durations and the clock (the headline above is untouched) ----
     sustained = None
     if a.sustained_seconds > 0:
-        sustained = sustained_run(runner, ex, dev, dist, frames_total, a.sustained_seconds, dt / a.steps, rank, world)
+        sustained = sustained_run(runner, ex, dev, dist, frames_total, a.sustained_seconds, rank, world)
         ex.device_status()
     # ---- the line checks itself: 8 frames of the last step that ran against the oracle; the gathered bytes against the packed ones ----
     verified, gather_verified, all_ok = None, None, True

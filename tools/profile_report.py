@@ -9,12 +9,19 @@ Per kernel of namespace orbfe:
   valu/salu/lds/vmem/smem per wave, waves   --pmc SQ_INSTS_* / SQ_WAVES
   issue_frac                                waves x valu_per_wave / (1024 SIMDs x 2.4 GHz / 2 cycles x avg duration)
   active/wait shares                        SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY, SQ_WAIT_ANY over SQ_WAVE_CYCLES
+  valu_busy                                 SQ_ACTIVE_INST_VALU (quad-cycles a wave spends on a VALU instruction, summed) x 4 /
+                                            (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the share of the SIMDs' time that goes into
+                                            vector instructions -- rocprofv3's VALUBusy (counter_defs.yaml) per kernel
+  effective_clock_mhz                       GRBM_GUI_ACTIVE / 8 / the kernel's average duration (MI355X_MICROARCH.md, DVFS
+                                            give-back; reads high on dispatches shorter than ~0.3 ms)
+  valu_cycles_per_instruction_weighted      tools/isa_mix.py: the kernel's emitted ISA priced with profiles/r03_valu_rate.txt
 Usage: profile_report.py <dir of profile_all.sh> <tag>"""
 import csv
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 from collections import defaultdict
 
@@ -111,9 +118,44 @@ for k, cs in sqb.items():
                    ("SQ_WAIT_ANY", "wait_any_share")):
         if cs.get(c):
             kern[k][key] = sum(cs[c]) / wc
+grbm = counters("grbm")
+for k, cs in grbm.items():
+    if "orbfe" not in k or not cs.get("GRBM_GUI_ACTIVE") or not cs.get("SQ_ACTIVE_INST_VALU"):
+        continue
+    n = len(cs["GRBM_GUI_ACTIVE"])
+    gui = sum(cs["GRBM_GUI_ACTIVE"]) / n / 8.0  # rocprofv3 sums the 8 XCDs
+    kern[k]["gui_cycles_per_launch"] = gui
+    kern[k]["valu_busy"] = sum(cs["SQ_ACTIVE_INST_VALU"]) / len(cs["SQ_ACTIVE_INST_VALU"]) * 4.0 / (SIMDS * gui)
+    if "avg_ms" in kern[k]:
+        kern[k]["effective_clock_mhz"] = gui / (kern[k]["avg_ms"] * 1e-3) / 1e6
+
+# the emitted ISA of the kernels the bench line prices (tools/isa_mix.py; hipcc is on the box)
+ISA = {"fast_blur_kernel<3>": ("kernels_fast.hip", "fast_blur_kernelILi3E"), "orient_brief_kernel": ("kernels_desc.hip", "orient_brief_kernel"),
+       "pyramid_kernel": ("kernels_pyramid.hip", "14pyramid_kernel"), "quadtree_kernel<512, false, 512>": ("kernels_quadtree.hip", "quadtree_kernelILi512ELb0ELi512E")}
+try:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_mix
+    for k in kern:
+        for pat, (f, sym) in ISA.items():
+            if k.endswith(pat):
+                try:
+                    mx = isa_mix.mix(os.path.join(ROOT, "orb_slam3_v1.0_amd", "csrc", f), sym)
+                except (SystemExit, OSError, subprocess.CalledProcessError) as e:
+                    kern[k]["isa_mix_error"] = str(e)[:200]
+                    continue
+                kern[k]["valu_cycles_per_instruction_weighted"] = mx["valu_cycles_per_instruction_weighted"]
+                kern[k]["isa_mix"] = {q: mx[q] for q in ("valu_static", "valu_static_fast_group", "valu_static_slow_group",
+                                                        "valu_static_priced_by_assumption", "salu_static", "lds_static")}
+                if kern[k].get("valu_per_wave") and kern[k].get("waves_per_launch") and kern[k].get("gui_cycles_per_launch"):
+                    # the dynamic count priced at the static mean, over the SIMD cycles the launch had
+                    kern[k]["issue_frac_weighted"] = (kern[k]["waves_per_launch"] * kern[k]["valu_per_wave"] * mx["valu_cycles_per_instruction_weighted"] /
+                                                      (SIMDS * kern[k]["gui_cycles_per_launch"]))
+except ImportError:
+    pass
 out["kernels"] = {k: kern[k] for k in sorted(kern, key=lambda k: -kern[k].get("pct_gpu_time", 0))}
 json.dump(out, open(os.path.join(root, "kernels.json"), "w"), indent=1)
 for k, v in out["kernels"].items():
-    print("%-44s avg %.3f ms  hbm %7.1f MB  valu/wave %6.0f salu %5.0f lds %4.0f  issue %.2f" % (
+    print("%-44s avg %.3f ms  hbm %7.1f MB  valu/wave %6.0f salu %5.0f lds %4.0f  issue %.2f  weighted %.2f  valu_busy %.2f  clk %4.0f MHz" % (
         k[-44:], v.get("avg_ms", 0), v.get("hbm_bytes_per_launch", 0) / 1e6, v.get("valu_per_wave") or 0,
-        v.get("salu_per_wave") or 0, v.get("lds_per_wave") or 0, v.get("issue_frac") or 0))
+        v.get("salu_per_wave") or 0, v.get("lds_per_wave") or 0, v.get("issue_frac") or 0, v.get("issue_frac_weighted") or 0,
+        v.get("valu_busy") or 0, v.get("effective_clock_mhz") or 0))
