@@ -59,6 +59,9 @@ WORKLOADS = {
     "euroc_752x480": (1000, 40000, 1.2, 8, 20, 7, 752, 480),
     # SURVEY.md section 8, SPEC DECISION S0: nFastFeatures = 16 x nFeatures (the default above is 40 x: no cap ever fires)
     "euroc_752x480_s0": (1000, 16000, 1.2, 8, 20, 7, 752, 480),
+    # the reference node's own ratio nFastFeatures = 1.6 x nFeatures (ros2_ws/src/mono-inertial/src/mono_inertial_node.cpp:88-89:
+    # 10000 / 16000): the per-level FAST cap fires on every level that holds more corners than that
+    "euroc_752x480_node": (1000, 1600, 1.2, 8, 20, 7, 752, 480),
     "batched_1280x720": (2000, 100000, 1.2, 8, 20, 7, 1280, 720),
     "tumvi_1024x1024": (1500, 100000, 1.2, 12, 20, 7, 1024, 1024),
 }

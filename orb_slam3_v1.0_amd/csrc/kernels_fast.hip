@@ -272,8 +272,9 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
                                                         int gray0Pitch, int gray0Aligned4,
                                                         uint8_t* __restrict__ ws, uint32_t* __restrict__ cand,
                                                         uint32_t* __restrict__ counters,
-                                                        uint32_t* __restrict__ tileTotals)
+                                                        uint16_t* __restrict__ tileRows)
 {
+    __shared__ uint32_t sRow[kFastTH];  // pre-NMS corners per tile row: low-pass count | high-pass count << 16
     __shared__ __attribute__((aligned(16))) uint8_t sImg[kImgH + 1][kImgW];  // + 1 spare row (the column walk of stage A reads at most row 39; kept so the arrays behind keep their offsets)
     __shared__ __attribute__((aligned(16))) uint32_t sTmp[kTmpH / 2][kFastTW];  // row pairs of horizontal sums
     __shared__ __attribute__((aligned(16))) uint8_t sScore[kScH + 1][kScPitch];
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     const int lane = tid & 63;
     if (tid < 4) sCnt[tid] = 0;
     if (tid < 3) sQ[tid] = 0;
+    if (tid < kFastTH) sRow[tid] = 0;
 
     // ---- stage the 72 x 40 tile (origin x0-4, y0-4).  Thread -> fixed dword column c4 (18 per row) and
     //      rows r0, r0+14, r0+28: the three loads are issued back to back.  Rows outside the level follow
@@ -643,6 +645,7 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
     //      wave on the scalar unit and reach LDS once, after the loop ----
     {
         uint32_t nPreW = 0, nPreHiW = 0, nKeepHiW = 0;
+        const uint32_t rowLds = (uint32_t)(uintptr_t)&sRow[0];
         const uint32_t candLds = (uint32_t)(uintptr_t)&sCand[0];
         constexpr uint32_t kIdleEntry = (uint32_t)(20 * kImgW + 36);  // an interior position: inactive lanes read valid LDS
 #pragma unroll 1
@@ -668,6 +671,8 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
             nPreW += (uint32_t)__popcll(mPre);
             nPreHiW += (uint32_t)__popcll(mPreHi);
             nKeepHiW += (uint32_t)__popcll(mKeepHi);
+            // pre-NMS corners per tile row (only read by the exact-cap path of the quadtree kernel): low | high << 16
+            masked_lds_add(mPre, rowLds + 4u * oy, select_by_mask(mHi, 0x10001u, 1u));
             if (mKeep) {  // wave-uniform
                 uint32_t wbase = 0;
                 if (lane == 0) wbase = lds_add_rtn(&sCnt[0], (uint32_t)__popcll(mKeep));
@@ -687,6 +692,16 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
 
     }  // MODE & 2
 
+    // per-tile-row pre-NMS counts, low pass | high pass << 8 (each <= 64, the tile's width): 64 B per tile, one coalesced store
+    // instruction (zero when FAST is ablated).  Only the exact-cap path of the quadtree kernel reads them.  One total per tile
+    // (4 B) with the row counts re-derived there was built and measured: this kernel -2.2 %, but the quadtree kernel 0.33 -> 0.81 ms
+    // per 512 frames at the reference node's nFast = 1.6 x nFeatures, where the cap fires on every level
+    // (profiles/r05_ab_experiments.json)
+    if (tid < kFastTH) {
+        const uint32_t v = sRow[tid];
+        tileRows[((size_t)f * P->totalTiles + tile) * kFastTH + tid] = (uint16_t)((v & 0xffu) | ((v >> 16) << 8));
+    }
+
     uint32_t* cnt = counters + ((size_t)f * nL + l) * kCntWords;
     const uint32_t nTile = sCnt[0];
     if (tid == 0) {
@@ -696,11 +711,6 @@ __global__ __launch_bounds__(256) void fast_blur_kernel(const PipelineDesc* __re
         if (sCnt[1]) atomicAdd(&cnt[kCntHigh], sCnt[1]);
         if (sCnt[2]) atomicAdd(&cnt[kCntPreLow], sCnt[2]);
         if (sCnt[3]) atomicAdd(&cnt[kCntPreHigh], sCnt[3]);
-        // pre-NMS corners of the tile, low pass | high pass << 16 (<= 2048 each): ONE word per tile.  Only the exact-cap path of
-        // the quadtree kernel reads it -- it finds the 32-row band in which a pass reaches nFast corners from these totals and
-        // recounts that band's rows itself (a per-row table cost 128 B per tile, 7 % of this kernel's written bytes, for a path
-        // that runs on the few levels with more than nFast corners)
-        tileTotals[(size_t)f * P->totalTiles + tile] = sCnt[2] | (sCnt[3] << 16);
         sBase = base;
     }
     __syncthreads();
@@ -724,13 +734,13 @@ uint32_t fast_tile_info(int level, int tileX, int tileY) { return ((uint32_t)lev
 
 void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint32_t* dTileInfo,
                       const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws,
-                      uint32_t* cand, uint32_t* counters, uint32_t* tileTotals)
+                      uint32_t* cand, uint32_t* counters, uint16_t* tileRows)
 {
     dim3 block(256);
     dim3 grid(frames, totalTiles);
 #define ORBFE_LAUNCH_FB(M)                                                                                          \
     hipLaunchKernelGGL(fast_blur_kernel<M>, grid, block, 0, s, dP, dTileInfo, gray0, gray0FrameStride, gray0Pitch, \
-                       gray0Aligned4, ws, cand, counters, tileTotals)
+                       gray0Aligned4, ws, cand, counters, tileRows)
 #ifdef ORBFE_ABLATION
     // timing-only build (liborbfe_ablation.so, `make ablation`): ORBFE_FAST_MODE selects a truncated kernel whose
     // RESULTS ARE WRONG unless it is 3.  The shipped library does not contain these variants and reads no variable.

@@ -86,23 +86,39 @@ __device__ __forceinline__ int block_excl_scan(int v, int& total, int* sWave)
 }
 
 // Exclusive raster-key bound of one FAST pass' pre-NMS cap: key of the nFast-th corner (raster order)
-// of this level, plus one.  The FAST kernel stored ONE total per 64 x 32 tile; the 32-row band in which the running count
-// reaches nFast follows from those, the row inside the band and the column inside the row from re-running the segment
-// test over that band (32 x w pixels) and along that row.  Block-wide, every thread returns the same value.  Only called
-// when the level has more than nFast corners.
+// of this level, plus one.  The cutoff row comes from the per-tile-row counts the FAST kernel
+// stored; the cutoff column from re-running the segment test along that single row.  Block-wide,
+// every thread returns the same value.  Only called when the level has more than nFast corners.
 template <int NT>
-__device__ __forceinline__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const LevelDesc& L, int f, int l, bool high,
+__device__ uint32_t pre_nms_cut_key(const PipelineDesc* __restrict__ P, const LevelDesc& L, int f, int l, bool high,
                                     int nFast, const uint8_t* __restrict__ gray0, size_t gray0FrameStride, int gray0Pitch,
-                                    const uint8_t* __restrict__ ws, const uint32_t* __restrict__ tileTotals, int* sWave,
+                                    const uint8_t* __restrict__ ws, const uint16_t* __restrict__ tileRows, int* sWave,
                                     int* sRed)
 {
-    static_assert(NT % kFastTH == 0, "band recount: one row per group of NT / 32 threads");
-    __shared__ int sBandRow[kFastTH];
     const int tid = threadIdx.x;
-    const uint32_t* tt = tileTotals + (size_t)f * P->totalTiles + L.tileBase;
-    if (tid == 0) { sRed[0] = -1; sRed[1] = 0; sRed[2] = -1; sRed[3] = -1; }
-    if (tid < kFastTH) sBandRow[tid] = 0;
+    const uint16_t* tr = tileRows + ((size_t)f * P->totalTiles + L.tileBase) * kFastTH;  // low pass | high pass << 8 per tile row
+    if (tid == 0) { sRed[0] = -1; sRed[1] = 0; sRed[2] = -1; }
     __syncthreads();
+    int carry = 0;
+    for (int base = 0; base < L.h; base += NT) {  // row where the running corner count reaches nFast
+        const int y = base + tid;
+        int c = 0;
+        if (y < L.h) {
+            const int ty = y / kFastTH, r = y % kFastTH;
+            for (int tx = 0; tx < L.tilesX; tx++) {
+                const uint32_t v = tr[(size_t)(ty * L.tilesX + tx) * kFastTH + r];
+                c += high ? (int)(v >> 8) : (int)(v & 0xffu);
+            }
+        }
+        int tot;
+        const int ex = block_excl_scan<NT>(c, tot, sWave) + carry;
+        if (c > 0 && ex < nFast && ex + c >= nFast) { sRed[0] = y; sRed[1] = nFast - ex; }  // exactly one thread
+        carry += tot;
+        __syncthreads();
+        if (sRed[0] >= 0) break;
+    }
+    const int ys = sRed[0], q = sRed[1];
+    if (ys < 0) return kKeyInf;
     const uint8_t* img;
     int pitch;
     if (l == 0) {
@@ -113,50 +129,6 @@ __device__ __forceinline__ uint32_t pre_nms_cut_key(const PipelineDesc* __restri
         pitch = L.pitch;
     }
     const int th = high ? P->iniTh : P->minTh;  // corner of the pass <=> score >= its threshold
-    int carry = 0;
-    for (int base = 0; base < L.tilesY; base += NT) {  // band (tile row) where the running corner count reaches nFast
-        const int ty = base + tid;
-        int c = 0;
-        if (ty < L.tilesY)
-            for (int tx = 0; tx < L.tilesX; tx++) {
-                const uint32_t v = tt[ty * L.tilesX + tx];
-                c += high ? (int)(v >> 16) : (int)(v & 0xffffu);
-            }
-        int tot;
-        const int ex = block_excl_scan<NT>(c, tot, sWave) + carry;
-        if (c > 0 && ex < nFast && ex + c >= nFast) { sRed[3] = ty; sRed[1] = nFast - ex; }  // exactly one thread
-        carry += tot;
-        __syncthreads();
-        if (sRed[3] >= 0) break;
-    }
-    const int band = sRed[3];
-    if (band < 0) return kKeyInf;
-    {
-        // corners per row of the band (the FAST region, Fast_gpu.cu:275,365-368): the block walks the band row by row, thread ->
-        // column (the row is block-uniform, so the sixteen ring row addresses are scalars: no registers held across the loop);
-        // one LDS add per wave and row
-        for (int r = 0; r < kFastTH; r++) {
-            const int y = band * kFastTH + r;
-            if (y <= kEdge || y >= L.h - kEdge) continue;  // block-uniform
-            for (int base = kEdge + 1; base < L.w - kEdge; base += NT) {
-                const int x = base + tid;
-                const bool flag = x < L.w - kEdge && corner_at_global(img, pitch, x, y, th);
-                const int c = __popcll(__ballot(flag));
-                if (c && (tid & 63) == 0) atomicAdd(&sBandRow[r], c);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {  // the row where the count inside the band reaches what is left of nFast
-            int left = sRed[1];
-            for (int i = 0; i < kFastTH; i++) {
-                if (sBandRow[i] >= left) { sRed[0] = band * kFastTH + i; sRed[1] = left; break; }
-                left -= sBandRow[i];
-            }
-        }
-        __syncthreads();
-    }
-    const int ys = sRed[0], q = sRed[1];
-    if (ys < 0) return kKeyInf;  // cannot happen: the band's tiles hold at least what is left of nFast
     carry = 0;
     for (int base = 0; base < L.w; base += NT) {  // the q-th corner of that row
         const int x = base + tid;
@@ -186,7 +158,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NC <= 512 ? 
                                                              uint32_t* __restrict__ lvlKp,
                                                              const uint8_t* __restrict__ gray0, size_t gray0FrameStride,
                                                              int gray0Pitch, const uint8_t* __restrict__ ws,
-                                                             const uint32_t* __restrict__ tileTotals,
+                                                             const uint16_t* __restrict__ tileRows,
                                                              uint8_t* __restrict__ scratch)
 {
     constexpr int IPT = NC / NT;  // nodes per thread in node-parallel steps
@@ -253,7 +225,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NC <= 512 ? 
     uint32_t cutHi = kKeyInf, cutLo = kKeyInf;
     int cH = (int)cnt[kCntHigh];
     if ((int)cnt[kCntPreHigh] > nFast) {
-        cutHi = pre_nms_cut_key<NT>(P, L, f, l, true, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileTotals, sWave, sRed);
+        cutHi = pre_nms_cut_key<NT>(P, L, f, l, true, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
         int c = 0;
         for (int p = tid; p < nAll; p += NT) c += cand_score(C[p]) >= iniTh && cand_key(C[p]) < cutHi;
         block_excl_scan<NT>(c, cH, sWave);
@@ -263,7 +235,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NC <= 512 ? 
     const bool retry = (double)diff > 0.25 * (double)nFast;
     int cL = nAll;
     if (retry && (int)cnt[kCntPreLow] > nFast) {
-        cutLo = pre_nms_cut_key<NT>(P, L, f, l, false, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileTotals, sWave, sRed);
+        cutLo = pre_nms_cut_key<NT>(P, L, f, l, false, nFast, gray0, gray0FrameStride, gray0Pitch, ws, tileRows, sWave, sRed);
         int c = 0;
         for (int p = tid; p < nAll; p += NT) c += cand_key(C[p]) < cutLo;
         block_excl_scan<NT>(c, cL, sWave);
@@ -610,7 +582,7 @@ size_t quadtree_scratch_bytes_per_block(int maxNodeCap)
 void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
                      const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp,
                      const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws,
-                     const uint32_t* tileTotals, uint8_t* scratch)
+                     const uint16_t* tileRows, uint8_t* scratch)
 {
     dim3 grid(frames, nLevels);
     // A call on one or a few frames is a handful of blocks on an empty chip and its time is the largest level's block:
@@ -619,16 +591,16 @@ void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, con
         dim3 blockS(kQtThreadsSmall);
         if (quadtree_node_capacity(maxNodeCap) <= 1024)
             hipLaunchKernelGGL((quadtree_kernel<1024, false, kQtThreadsSmall>), grid, blockS, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
-                               gray0FrameStride, gray0Pitch, ws, tileTotals, scratch);
+                               gray0FrameStride, gray0Pitch, ws, tileRows, scratch);
         else
             hipLaunchKernelGGL((quadtree_kernel<2048, false, kQtThreadsSmall>), grid, blockS, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0,
-                               gray0FrameStride, gray0Pitch, ws, tileTotals, scratch);
+                               gray0FrameStride, gray0Pitch, ws, tileRows, scratch);
         return;
     }
     dim3 block(kQtThreads);
 #define ORBFE_QT(NCV, GLB)                                                                                        \
     hipLaunchKernelGGL((quadtree_kernel<NCV, GLB>), grid, block, 0, s, dP, cand, nodeOf, counters, lvlKp, gray0, \
-                       gray0FrameStride, gray0Pitch, ws, tileTotals, scratch)
+                       gray0FrameStride, gray0Pitch, ws, tileRows, scratch)
     switch (quadtree_node_capacity(maxNodeCap)) {
     case 512: ORBFE_QT(512, false); break;
     case 2048: ORBFE_QT(2048, false); break;

@@ -24,7 +24,7 @@ void fast_tiles_for(int w, int h, int* tx, int* ty);
 uint32_t fast_tile_info(int level, int tileX, int tileY);  // entry of the per-tile table (level << 24 | ty << 12 | tx)
 void launch_fast_blur(hipStream_t s, int frames, int totalTiles, const PipelineDesc* dP, const uint32_t* dTileInfo,
                       const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, int gray0Aligned4, uint8_t* ws,
-                      uint32_t* cand, uint32_t* counters, uint32_t* tileTotals);
+                      uint32_t* cand, uint32_t* counters, uint16_t* tileRows);
 
 // kernels_quadtree.hip
 int quadtree_node_capacity(int maxNodeCap);
@@ -32,7 +32,7 @@ size_t quadtree_scratch_bytes_per_block(int maxNodeCap);
 void launch_quadtree(hipStream_t s, int frames, int nLevels, int maxNodeCap, const PipelineDesc* dP,
                      const uint32_t* cand, uint16_t* nodeOf, uint32_t* counters, uint32_t* lvlKp,
                      const uint8_t* gray0, size_t gray0FrameStride, int gray0Pitch, const uint8_t* ws,
-                     const uint32_t* tileTotals, uint8_t* scratch);
+                     const uint16_t* tileRows, uint8_t* scratch);
 
 // kernels_desc.hip
 void launch_orient_brief(hipStream_t s, int frames, int kpCapFrame, const PipelineDesc* dP, const uint8_t* gray0,

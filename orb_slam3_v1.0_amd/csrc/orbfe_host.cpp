@@ -61,7 +61,7 @@ struct orbfe_handle {
     size_t candWordsPerBatch = 0;
     uint32_t* dCounters = nullptr;  // [frame][level][kCntWords]
     uint32_t* dLvlKp = nullptr;     // [frame][kpCapFrame]
-    uint32_t* dTileRows = nullptr;  // [frame][FAST tile] pre-NMS corners of the tile: low pass | high pass << 16
+    uint16_t* dTileRows = nullptr;  // [frame][FAST tile][32] pre-NMS corner counts per tile row: low pass | high pass << 8
     uint8_t* dQtScratch = nullptr;  // node tables of the large-N quadtree variant, [level][frame] slabs
     uint32_t* dTabs = nullptr;      // resize tables
     uint32_t* dTileInfo = nullptr;  // FAST tile -> (level, tile column, tile row)
@@ -428,7 +428,7 @@ int orbfe_create(const orbfe_params* p, orbfe_handle** out)
     CREATE_CHK(hipMalloc(&h->dNodeOf, candOff * sizeof(uint16_t)));
     CREATE_CHK(hipMalloc(&h->dCounters, B * nL * kCntWords * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc(&h->dLvlKp, B * (size_t)P.kpCapFrame * sizeof(uint32_t)));
-    CREATE_CHK(hipMalloc(&h->dTileRows, B * (size_t)P.totalTiles * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc(&h->dTileRows, B * (size_t)P.totalTiles * 32 * sizeof(uint16_t)));
     if (quadtree_scratch_bytes_per_block(h->maxNodeCap))
         CREATE_CHK(hipMalloc(&h->dQtScratch, quadtree_scratch_bytes_per_block(h->maxNodeCap) * B * nL));
     CREATE_CHK(hipMalloc(&h->dTabs, tabs.size() * sizeof(uint32_t)));
