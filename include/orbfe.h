@@ -520,6 +520,28 @@ int orbfe_fuse_search(orbfe_handle *h, const orbfe_frame_view *KF, const float *
                       const orbfe_world_point *points, const uint8_t *mp_desc, int *best_idx_out,
                       int *best_dist_out);
 
+/* What the projection searches INTO a resident key frame read besides orbfe_keyframe_create's arrays: mGrid (the geometry of
+ * orbfe_frame_view: grid_cols x grid_rows cells from (min_x, min_y) with the inverse cell sizes, src/KeyFrame.cc:33-80 copies them
+ * from the Frame), mvInvLevelSigma2 (n_levels floats) and mvuRight (n floats, or NULL == monocular).  The per-level cell
+ * tables are built here, ONCE, and stay with the key frame; calling it again replaces them.  HOST pointers; synchronises. */
+int orbfe_keyframe_set_grid(orbfe_handle *h, orbfe_keyframe *kf, int grid_cols, int grid_rows, float min_x, float min_y,
+                            float grid_inv_w, float grid_inv_h, const float *inv_level_sigma2, const float *u_right);
+
+/* orbfe_fuse_search on RESIDENT data -- LocalMapping::SearchInNeighbors (src/LocalMapping.cc:764-860) calls
+ * ORBmatcher::Fuse(pKFi, vpMapPointMatches) for every neighbour and Fuse(mpCurrentKeyFrame, vpFuseCandidates) once
+ * (:822,:852): up to 2 x 30 calls per new key frame, every one of which re-uploaded its target key frame (56 B per feature)
+ * and its map points (64 B each) through orbfe_fuse_search although both already sit in HBM.  Here the target is a key
+ * frame of orbfe_keyframe_create with orbfe_keyframe_set_grid done, the map points are entries of an orbfe_map named by id:
+ * ids[i] >= 0 = the entry; ~id (negative) = the entry with "!pMP || pMP->IsInKeyFrame(pKF)" for this call (skipped,
+ * src/ORBmatcher.cc:706-721); an id outside the map = no point.  Up go the frustum and 4 bytes per map point, down come
+ * best_idx_out[i] / best_dist_out[i] as orbfe_fuse_search (-1 / 256 when nothing qualified).  The calls of one
+ * SearchInNeighbors stay sequential -- between two of them the caller replaces / adds map points (:829-849); descriptor
+ * and position changes reach the map through orbfe_map_update, which is ordered in front of the next call.
+ * Same results as orbfe_fuse_search on the same key frame, map points and flags (monocular / stereo left camera; the bRight
+ * overload has no resident form). */
+int orbfe_fuse_search_keyframe(orbfe_handle *h, const orbfe_keyframe *kf, const orbfe_map *map, int M, const int *ids,
+                               const orbfe_frustum *frustum, float th, int *best_idx_out, int *best_dist_out);
+
 /* the same with bRight = true (src/ORBmatcher.cc:684-688,:820; callers src/LocalMapping.cc:824,854 when the key frame
  * has a second camera): frustum carries pKF->GetRightPose() / GetRightTranslationInverse() / mpCamera2; KF_left
  * describes the LEFT features (KF_left->n == pKF->NLeft -- they fill mGrid, and the level and chi-square gates read them,
@@ -656,6 +678,35 @@ int orbfe_track_reference_keyframe(orbfe_handle *h, const uint8_t *gray, int pit
                                    int check_orientation, orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out,
                                    int *per_level_counts, int *word_id_out, int *node_id_out, double *weight_out,
                                    int *match_out, int *n_matches);
+
+/* -------------------------------------------------------------------------------------------
+ * The tracking thread's chain of a frame during monocular initialisation, as ONE submission
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orbfe_init_frame orbfe_init_frame;
+
+/* mInitialFrame of Tracking::MonocularInitialization (src/Tracking.cc:569-586: the first frame with more than FEAT_INIT_COUNT
+ * keypoints becomes the reference every following frame is matched against until the map is initialised or the attempt is
+ * reset, :588-602), resident in HBM: its mvKeysUn (n keypoints) and mDescriptors (n x 32).  HOST pointers; one upload.
+ * The frame stays on the device until orbfe_init_frame_destroy (which waits for the device). */
+int orbfe_init_frame_create(orbfe_handle *h, int n, const orbfe_keypoint *kp, const uint8_t *desc, orbfe_init_frame **out);
+void orbfe_init_frame_destroy(orbfe_init_frame *f);
+int orbfe_init_frame_size(const orbfe_init_frame *f);
+
+/* replaces, for one frame while the map is being initialised (Tracking::MonocularInitialization, src/Tracking.cc:566-607):
+ *   Frame::Frame -> ExtractORB -> ORBextractor::extractFeatures                                          (src/Frame.cc:178-189)
+ *   ORBmatcher::SearchForInitialization(mInitialFrame, mCurrentFrame, windowSize, nnRatio, true)         (src/ORBmatcher.cc:329-439;
+ *                                                                                          the call: src/Tracking.cc:603-607, 40 / 0.45)
+ * gray / pitch / kp_out / desc_out / n_out / per_level_counts as orbfe_extract; tp: the CURRENT frame's grid statics
+ * (GetFeaturesInArea runs on frame 2; th / nn_ratio / far_points of the block are not read); matches12_out
+ * (orbfe_init_frame_size(f1) ints) = vnMatches12 (index in the current frame or -1), *n_matches = the function's return value.
+ * The thresholds around the call (FEAT_INIT_COUNT, the 2 s time-out, :579,:588-598) stay with the caller.
+ * One captured hipGraph per (initial frame, input pitch, parameters): extraction kernels, the matcher's kernels on the fresh
+ * keypoints, ONE result block back, one synchronisation.  Byte-identical to orbfe_extract followed by
+ * orbfe_match_initialization(f1, current frame).  HOST pointers; gray may be pinned (read in place) or pageable. */
+int orbfe_track_initialization(orbfe_handle *h, const uint8_t *gray, int pitch, const orbfe_init_frame *f1,
+                               const orbfe_track_params *tp, int window_size, float nn_ratio, int check_orientation,
+                               orbfe_keypoint *kp_out, uint8_t *desc_out, int *n_out, int *per_level_counts,
+                               int *matches12_out, int *n_matches);
 
 /* -------------------------------------------------------------------------------------------
  * Misc

@@ -32,7 +32,9 @@ constexpr int kFastCand = 8192;   // candidate keys of the rows longer than four
 
 struct InitRowHdr;
 struct InitArgs {
-    int n1, n2;
+    int n1, n2;       // n2: frame 2's keypoint count -- or, with n2Dev set, its capacity (the count is still on the device)
+    const int* n2Dev; // fused per-frame chain (init_track_launch): the extraction that runs in front wrote the count here
+    int candStride;   // row stride of `cand` (n2 on the host path, the capacity on the fused one)
     const orbfe_keypoint* kp1;
     const uint8_t* desc1;
     const orbfe_keypoint* kp2;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(kInitThreads) void init_match_kernel(InitArgs A)
     __shared__ int sWave[kInitThreads / 64];
     __shared__ int sN0, sNm, sInd[3];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n1 = A.n1, n2 = A.n2;
+    const int n1 = A.n1, n2 = A.n2Dev ? min(*A.n2Dev, A.n2) : A.n2;
 
     // ---- frame 2: grid cell per keypoint (Frame::PosInGrid, src/Frame.cc:470-480) + state ----
     for (int j = tid; j < n2; j += kInitThreads) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void init_cand_kernel(InitArgs A, int n0)
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // row == position in frame 1's level-0 list
     if (t >= n0) return;
-    const int n2 = A.n2;
+    const int n2 = A.n2Dev ? min(*A.n2Dev, A.n2) : A.n2;
     const int i1 = A.list0[t];
     const orbfe_keypoint k1p = A.kp1[i1];
     // GetFeaturesInArea(x, y, windowSize, level1, level1) on frame 2, src/Frame.cc:413-435
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void init_cand_kernel(InitArgs A, int n0)
     if (any) {
         const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(A.desc1 + (size_t)i1 * 32);
         const unsigned long long d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
-        unsigned long long* row = A.cand + (size_t)t * n2;
+        unsigned long long* row = A.cand + (size_t)t * A.candStride;
         for (int j0 = 0; j0 < n2; j0 += 64) {
             const int j = j0 + lane;
             bool ok = j < n2;
@@ -340,8 +342,9 @@ struct FastState {
     float angle2[kInitN];
     int i1[kFastN0];                // level-0 keypoints of frame 1 in index order
     float angle1[kFastN0];
-    int off[kFastN0];
+    int off[kFastN0];               // row offsets in sCand; after the ordered loop: the rotation bin of the row's accepted match
     int cnt[kFastN0];
+    short acc[kFastN0];             // the frame-2 keypoint row t accepted (:383-406), -1 = none -- whoever owns it in the end
     unsigned long long top[kFastN0][4];
 };
 
@@ -353,22 +356,20 @@ __global__ __launch_bounds__(kInitThreads) void init_order_kernel(InitArgs A, in
     __shared__ int sWave[kInitThreads / 64];
     __shared__ int sNm, sTotal, sInd[3];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n1 = A.n1, n2 = A.n2;
+    const int n1 = A.n1, n2 = A.n2Dev ? min(*A.n2Dev, A.n2) : A.n2;
     for (int j = tid; j < n2; j += kInitThreads) {
         T.dist[j] = 0xFFFF;
         T.matched21[j] = -1;
         T.angle2[j] = A.kp2[j].angle;
     }
-    for (int i = tid; i < n1; i += kInitThreads) {
-        A.matches12[i] = -1;
-        A.binOf[i] = -1;
-    }
+    for (int i = tid; i < n1; i += kInitThreads) A.matches12[i] = -1;
     for (int t = tid; t < n0; t += kInitThreads) {
         const int i1 = A.list0[t];
         const InitRowHdr h = A.hdr[t];
         T.i1[t] = i1;
         T.angle1[t] = A.kp1[i1].angle;
         T.cnt[t] = h.cnt;
+        T.acc[t] = -1;
         T.top[t][0] = h.top[0]; T.top[t][1] = h.top[1]; T.top[t][2] = h.top[2]; T.top[t][3] = h.top[3];
     }
     if (tid < ORBFE_HISTO_LENGTH) sHist[tid] = 0;
@@ -407,21 +408,31 @@ __global__ __launch_bounds__(kInitThreads) void init_order_kernel(InitArgs A, in
         for (int t = wv; t < n0; t += kInitThreads / 64) {
             const int c = T.cnt[t], o = T.off[t];
             if (c <= 4) continue;
-            const unsigned long long* row = A.cand + (size_t)t * n2;
+            const unsigned long long* row = A.cand + (size_t)t * A.candStride;
             for (int k = lane; k < c; k += 64) sCand[o + k] = row[k];
         }
     }
     __syncthreads();
 
-    // ---- the order-dependent part, one wave ----
-    if (wv == 0) {
-        const float factor = 1.0f / ORBFE_HISTO_LENGTH;
+    // ---- the order-dependent part, one wave.  The running state is vMatchedDistance and vnMatches21 alone: vnMatches12, the
+    //      match count and the rotation histogram follow from "which row accepted which keypoint" (T.acc) and "who owns it in
+    //      the end" (T.matched21) and are derived by all threads afterwards -- a row accepts at most once, its match survives iff
+    //      nobody took the keypoint later (:387-391), and the histogram counts every accept, stolen later or not (:395-405).
+    //      A step is then one dependent LDS read (the targets' distances) between the prefetched row header and three LDS
+    //      writes by lane 0; the LDS executes a wave's operations in order, so the next step's reads see them ----
+    if (wv == 0 && n0 > 0) {
+        unsigned long long keyN = lane < 4 ? T.top[0][lane] : kKeyNone;
+        int cN = T.cnt[0];
         for (int t = 0; t < n0; t++) {
-            const int c = T.cnt[t];
+            const unsigned long long key = keyN;
+            const int c = cN;
+            if (t + 1 < n0) {  // the next row's header does not depend on the state: requested a step ahead
+                keyN = lane < 4 ? T.top[t + 1][lane] : kKeyNone;
+                cN = T.cnt[t + 1];
+            }
             if (c == 0) continue;  // wave-uniform
             unsigned long long k1 = kKeyNone, k2 = kKeyNone;
             {
-                const unsigned long long key = lane < 4 ? T.top[t][lane] : kKeyNone;
                 bool pass = false;
                 if (key != kKeyNone) {
                     const int j = (int)(key & 0xFFFFF), dist = (int)(key >> 52);
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(kInitThreads) void init_order_kernel(InitArgs A, in
                         if (m2) k2 = readlane_u64(key, __builtin_ctzll(m2));
                     }
                 } else {  // fewer than two of the pre-selected keys are usable: reduce the whole row
-                    const unsigned long long* L = inLds ? sCand + T.off[t] : A.cand + (size_t)t * n2;
+                    const unsigned long long* L = inLds ? sCand + T.off[t] : A.cand + (size_t)t * A.candStride;
                     for (int k = lane; k < c; k += 64) {
                         const unsigned long long kk = L[k];
                         const int j = (int)(kk & 0xFFFFF), dist = (int)(kk >> 52);
@@ -450,31 +461,31 @@ __global__ __launch_bounds__(kInitThreads) void init_order_kernel(InitArgs A, in
                 const int bestDist = (int)(k1 >> 52), bestIdx2 = (int)(k1 & 0xFFFFF);
                 const int bestDist2 = k2 == kKeyNone ? kIntMax : (int)(k2 >> 52);
                 if (bestDist <= ORBFE_TH_LOW && (float)bestDist < (float)bestDist2 * A.nnRatio) {  // :383-385
-                    const int i1 = T.i1[t];
-                    const int prev = T.matched21[bestIdx2];
-                    if (prev >= 0) { A.matches12[T.i1[prev]] = -1; sNm--; }
-                    A.matches12[i1] = bestIdx2;
-                    T.matched21[bestIdx2] = (short)t;  // position in the level-0 list (< kFastN0)
+                    T.matched21[bestIdx2] = (short)t;  // position in the level-0 list (< kFastN0); the previous owner loses it
                     T.dist[bestIdx2] = (unsigned short)bestDist;
-                    sNm++;
-                    if (A.checkOrientation) {
-                        float rot = T.angle1[t] - T.angle2[bestIdx2];
-                        if (rot < 0.0) rot = rot + 360.0f;
-                        int bin = (int)roundf(rot * factor);
-                        if (bin == ORBFE_HISTO_LENGTH) bin = 0;
-                        sHist[bin]++;
-                        A.binOf[i1] = bin;
-                    }
+                    T.acc[t] = (short)bestIdx2;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // lane 0's LDS updates before the next step's reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 0's LDS updates stay in front of the next step's reads
             __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
 
-    // ---- rotation histogram filter (:411-435; ComputeThreeMaxima :1328-1370) ----
+    // ---- rotation histogram over every accept (:395-405), ComputeThreeMaxima (:1328-1370) ----
     if (A.checkOrientation) {
+        const float factor = 1.0f / ORBFE_HISTO_LENGTH;
+        for (int t = tid; t < n0; t += kInitThreads) {
+            const int j = T.acc[t];
+            if (j < 0) continue;
+            float rot = T.angle1[t] - T.angle2[j];
+            if (rot < 0.0) rot = rot + 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+            atomicAdd(&sHist[bin], 1);
+            T.off[t] = bin;  // (the row offsets are no longer needed)
+        }
+        __syncthreads();
         if (tid == 0) {
             int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
             for (int i = 0; i < ORBFE_HISTO_LENGTH; i++) {
@@ -488,15 +499,22 @@ __global__ __launch_bounds__(kInitThreads) void init_order_kernel(InitArgs A, in
             sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
         }
         __syncthreads();
-        for (int i = tid; i < n1; i += kInitThreads) {
-            const int b = A.binOf[i];
-            if (b >= 0 && b != sInd[0] && b != sInd[1] && b != sInd[2] && A.matches12[i] >= 0) {
-                A.matches12[i] = -1;
-                atomicSub(&sNm, 1);
-            }
-        }
-        __syncthreads();
     }
+    // ---- vnMatches12 and the count: keypoint j of frame 2 belongs to the row that owns it in the end, unless the rotation
+    //      filter drops that row's bin (:411-435) ----
+    int local = 0;
+    for (int j = tid; j < n2; j += kInitThreads) {
+        const int t = T.matched21[j];
+        if (t < 0) continue;
+        if (A.checkOrientation) {
+            const int b = T.off[t];
+            if (b != sInd[0] && b != sInd[1] && b != sInd[2]) continue;
+        }
+        A.matches12[T.i1[t]] = j;
+        local++;
+    }
+    if (local) atomicAdd(&sNm, local);
+    __syncthreads();
     if (tid == 0) *A.nMatches = sNm;
 }
 
@@ -546,6 +564,8 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
     InitArgs A{};
     A.n1 = n1; A.n2 = n2;
+    A.n2Dev = nullptr;
+    A.candStride = n2;
     A.kp1 = reinterpret_cast<const orbfe_keypoint*>(dp + oKp1);
     A.desc1 = dp + oD1;
     A.kp2 = reinterpret_cast<const orbfe_keypoint*>(dp + oKp2);
@@ -581,6 +601,77 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
     MCHK(hipStreamSynchronize(s));
     memcpy(matches12Out, hOut, (size_t)n1 * sizeof(int));
     *nMatches = *reinterpret_cast<int*>(hOut + (oNM - oM12));
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused form (orbfe_track_initialization): frame 1 is the RESIDENT initial frame (mInitialFrame, Tracking.cc:569-602),
+// frame 2 the current frame whose keypoints, descriptors and count the extraction chain wrote a kernel earlier.  No copy,
+// no synchronisation: capturable.  The same kernels as match_initialization_run, with frame 2's count read on the device.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct InitTrackCarve {
+    size_t oM21, oMD, oCell, oBin, oCand, oHdr, bytes;
+    bool fast;
+};
+InitTrackCarve init_track_carve(int n1, int n0, int cap)
+{
+    InitTrackCarve C{};
+    Carver c;
+    C.fast = cap <= kInitN && n0 <= kFastN0;
+    C.oM21 = c.take((size_t)cap * sizeof(int));
+    C.oMD = c.take((size_t)cap * sizeof(int));
+    C.oCell = c.take((size_t)cap * sizeof(int));
+    C.oBin = c.take((size_t)std::max(n1, 1) * sizeof(int));
+    C.oCand = c.take(C.fast ? (size_t)std::max(n0, 1) * cap * sizeof(unsigned long long) : 8);
+    C.oHdr = c.take(C.fast ? (size_t)std::max(n0, 1) * sizeof(InitRowHdr) : 8);
+    C.bytes = c.off;
+    return C;
+}
+}  // namespace
+
+size_t init_track_scratch_bytes(int n1, int n0, int cap) { return init_track_carve(n1, n0, cap).bytes; }
+
+int init_track_launch(hipStream_t s, int n1, int n0, const orbfe_keypoint* dKp1, const uint8_t* dDesc1, const int* dList0,
+                      const orbfe_keypoint* dKp2, const uint8_t* dDesc2, const int* dN2, int cap, int gridCols, int gridRows,
+                      float minX, float minY, float invW, float invH, int windowSize, float nnRatio, int checkOrientation,
+                      int* dMatches12, int* dNMatches, uint8_t* scratch, std::string& err)
+{
+    if (cap >= (1 << 20) || gridCols > 65535 || gridRows > 32767) return ORBFE_ERR_UNSUPPORTED;
+    const InitTrackCarve C = init_track_carve(n1, n0, cap);
+    InitArgs A{};
+    A.n1 = n1; A.n2 = cap;
+    A.n2Dev = dN2;
+    A.candStride = cap;
+    A.kp1 = dKp1; A.desc1 = dDesc1;
+    A.kp2 = dKp2; A.desc2 = dDesc2;
+    A.cols = gridCols; A.rows = gridRows;
+    A.minX = minX; A.minY = minY; A.invW = invW; A.invH = invH;
+    A.r = (float)windowSize;
+    A.nnRatio = nnRatio;
+    A.checkOrientation = checkOrientation;
+    A.matches12 = dMatches12;
+    A.nMatches = dNMatches;
+    A.matched21 = reinterpret_cast<int*>(scratch + C.oM21);
+    A.matchedDist = reinterpret_cast<int*>(scratch + C.oMD);
+    A.cell2 = reinterpret_cast<int*>(scratch + C.oCell);
+    A.list0 = const_cast<int*>(dList0);  // (read only on the fast path; the sequential kernel rebuilds the same list in place)
+    A.binOf = reinterpret_cast<int*>(scratch + C.oBin);
+    A.cand = reinterpret_cast<unsigned long long*>(scratch + C.oCand);
+    A.hdr = reinterpret_cast<InitRowHdr*>(scratch + C.oHdr);
+    if (n1 == 0) {  // nothing to match: the count only (matches12 has no entries)
+        MCHK(hipMemsetAsync(dNMatches, 0, sizeof(int), s));
+        return ORBFE_OK;
+    }
+    if (C.fast) {
+        if (n0 > 0) hipLaunchKernelGGL(init_cand_kernel, dim3((n0 + 3) / 4), dim3(256), 0, s, A, n0);
+        hipLaunchKernelGGL(init_order_kernel, dim3(1), dim3(kInitThreads), 0, s, A, n0);
+    } else if (cap <= kInitN) {
+        hipLaunchKernelGGL(init_match_kernel<true>, dim3(1), dim3(kInitThreads), 0, s, A);
+    } else {
+        hipLaunchKernelGGL(init_match_kernel<false>, dim3(1), dim3(kInitThreads), 0, s, A);
+    }
+    MCHK(hipGetLastError());
     return ORBFE_OK;
 }
 

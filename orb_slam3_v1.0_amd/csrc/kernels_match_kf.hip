@@ -11,6 +11,7 @@
 #include "device_math.h"
 #include "match_common.h"
 #include "match_proj.h"
+#include "keyframe.h"
 
 #pragma clang fp contract(off)
 
@@ -26,7 +27,11 @@ namespace {
 // PredictScale, KeyFrame::GetFeaturesInArea through the per-level cell-range tables, the chi-square gate
 // (:794-817) and the nearest descriptor under (distance, visit position) == the reference's strict "<" scan.
 // ---------------------------------------------------------------------------------------------
+// GATHER: the map points are entries ids[i] of a resident map of mapCap entries (orbfe_map): id >= 0 the entry, ~id (negative)
+// the entry with this call's skip flag set, outside the map no point -- pts / mpDesc are then the map's arrays.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frustum F, float th, int M,
+                                                          const int* __restrict__ ids, int mapCap,
                                                           const orbfe_world_point* __restrict__ pts,
                                                           const uint8_t* __restrict__ mpDesc,
                                                           const float* __restrict__ invLevelSigma2,
@@ -36,10 +41,18 @@ __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frus
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (one wave per block for a single call: see fuse_search_run)
     if (i >= M) return;
-    const orbfe_world_point p = pts[i];
+    int src = i;
+    bool skipped = false;
+    if (GATHER) {
+        const int id = ids[i];
+        src = id < 0 ? ~id : id;
+        skipped = id < 0 || src >= mapCap;
+        if (src >= mapCap) src = 0;
+    }
+    const orbfe_world_point p = pts[src];
     int bestIdx = -1, bestDist = 256;
     do {
-        if (p.skip || p.bad) break;  // :706-721
+        if (skipped || (!GATHER && p.skip) || p.bad) break;  // :706-721 (a resident entry's own skip member is per frame: ignored)
         const float X = p.x, Y = p.y, Z = p.z;
         const float pcx = ((F.rcw[0] * X + F.rcw[1] * Y) + F.rcw[2] * Z) + F.tcw[0];
         const float pcy = ((F.rcw[3] * X + F.rcw[4] * Y) + F.rcw[5] * Z) + F.tcw[1];
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(256) void fuse_search_kernel(ProjArgs A, orbfe_frus
         w.r = th * A.scaleFactors[lvl];  // :766
         window_cells(A.g, w);
         if (!w.valid) break;
-        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(mpDesc + (size_t)i * 32);
+        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(mpDesc + (size_t)src * 32);
         const unsigned long long d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
         const int tabStride = A.g.cols + 1;
         uint32_t best = kKey32None;
@@ -379,13 +392,93 @@ int fuse_search_run(MatchScratch& m, hipStream_t s, const orbfe_frame_view* KF, 
     A.matchOut = reinterpret_cast<int*>(dp + oMatch);
     proj_prepare_launch(s, A, false);
     int* dBest = reinterpret_cast<int*>(dp + oBest);
-    hipLaunchKernelGGL(fuse_search_kernel, dim3((M + 63) / 64), dim3(64), 0, s, A, *F, th, M,
+    hipLaunchKernelGGL(fuse_search_kernel<false>, dim3((M + 63) / 64), dim3(64), 0, s, A, *F, th, M, nullptr, 0,
                        reinterpret_cast<const orbfe_world_point*>(dp + oPts), dp + oMpDesc,
                        reinterpret_cast<const float*>(dp + oIs2), uRight ? reinterpret_cast<const float*>(dp + oUr) : nullptr,
                        chi2Gate, nRight >= 0 ? reinterpret_cast<const unsigned long long*>(dp + oRight) : nullptr, nRight, dBest,
                        dBest + M);
     MCHK(hipGetLastError());
     int* hBest = reinterpret_cast<int*>(hp + inBytes);
+    MCHK(hipMemcpyAsync(hBest, dBest, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    MCHK(hipStreamSynchronize(s));
+    memcpy(bestIdxOut, hBest, (size_t)M * sizeof(int));
+    memcpy(bestDistOut, hBest + M, (size_t)M * sizeof(int));
+    return ORBFE_OK;
+}
+
+int keyframe_set_grid(KeyFrameDev* K, hipStream_t s, int gridCols, int gridRows, float minX, float minY, float invW, float invH,
+                      const float* invLevelSigma2, const float* uRight, std::string& err)
+{
+    if (!K || !invLevelSigma2 || gridCols < 1 || gridRows < 1) return ORBFE_ERR_INVALID_ARG;
+    const int n = K->n;
+    if (n >= (1 << 20) || gridCols > 65535 || gridRows > 32767 || (long long)gridCols * gridRows > kMaxCells) return ORBFE_ERR_UNSUPPORTED;
+    K->hasGrid = false;
+    Carver in;
+    const size_t oN = in.take(sizeof(int));
+    const size_t oIs2 = in.take((size_t)K->nLevels * sizeof(float));
+    const size_t oUr = in.take((size_t)std::max(n, 1) * sizeof(float));
+    const size_t inBytes = in.off;
+    const size_t oMatch = in.take((size_t)std::max(n, 1) * sizeof(int));  // the grid kernel clears a match array
+    ProjArgs A{};
+    A.B = 1; A.M = 1; A.kpStride = std::max(n, 1);
+    A.g = GridDesc{gridCols, gridRows, minX, minY, invW, invH};
+    A.nnRatio = 1.0f;
+    A.nLevels = K->nLevels;
+    int rc = proj_setup(K->gridMem, A, in, inBytes, err);
+    if (rc != ORBFE_OK) return rc;
+    uint8_t* hp = static_cast<uint8_t*>(K->gridMem.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(K->gridMem.d);
+    memcpy(hp + oN, &n, sizeof(int));
+    memcpy(hp + oIs2, invLevelSigma2, (size_t)K->nLevels * sizeof(float));
+    if (uRight && n) memcpy(hp + oUr, uRight, (size_t)n * sizeof(float));
+    MCHK(hipMemcpyAsync(dp, hp, inBytes, hipMemcpyHostToDevice, s));
+    A.kp = K->kp;
+    A.desc = K->desc;
+    A.nKp = reinterpret_cast<const int*>(dp + oN);
+    A.scaleFactors = K->sf;
+    A.matchOut = reinterpret_cast<int*>(dp + oMatch);
+    if (n) proj_prepare_launch(s, A, false);
+    MCHK(hipGetLastError());
+    MCHK(hipStreamSynchronize(s));
+    (void)hipHostFree(K->gridMem.hpin);  // the staging block has done its work; the device arena stays with the key frame
+    K->gridMem.hpin = nullptr;
+    K->gridMem.hBytes = 0;
+    K->grid = A;
+    K->invLevelSigma2 = reinterpret_cast<const float*>(dp + oIs2);
+    K->uRight = uRight ? reinterpret_cast<const float*>(dp + oUr) : nullptr;
+    K->hasGrid = true;
+    return ORBFE_OK;
+}
+
+int fuse_search_keyframe_run(MatchScratch& m, hipStream_t s, const KeyFrameDev* K, int mapCap, const orbfe_world_point* mapPts,
+                             const uint8_t* mapDesc, int M, const int* ids, const orbfe_frustum* F, float th, int* bestIdxOut,
+                             int* bestDistOut, std::string& err)
+{
+    for (int i = 0; i < M; i++) {
+        bestIdxOut[i] = -1;
+        bestDistOut[i] = 256;
+    }
+    if (!K->hasGrid) {
+        err = "orbfe_fuse_search_keyframe: the key frame has no grid (orbfe_keyframe_set_grid)";
+        return ORBFE_ERR_INVALID_ARG;
+    }
+    if (K->n == 0 || M == 0) return ORBFE_OK;
+    if (F->n_levels > K->nLevels) return ORBFE_ERR_INVALID_ARG;  // predicted levels index the key frame's scale tables
+    Carver c;
+    const size_t oIds = c.take((size_t)M * sizeof(int));
+    const size_t oBest = c.take((size_t)M * 2 * sizeof(int));
+    int rc = ensure(m, c.off, c.off, err);
+    if (rc != ORBFE_OK) return rc;
+    uint8_t* hp = static_cast<uint8_t*>(m.hpin);
+    uint8_t* dp = static_cast<uint8_t*>(m.d);
+    memcpy(hp + oIds, ids, (size_t)M * sizeof(int));
+    MCHK(hipMemcpyAsync(dp + oIds, hp + oIds, (size_t)M * sizeof(int), hipMemcpyHostToDevice, s));
+    int* dBest = reinterpret_cast<int*>(dp + oBest);
+    hipLaunchKernelGGL(fuse_search_kernel<true>, dim3((M + 63) / 64), dim3(64), 0, s, K->grid, *F, th, M,
+                       reinterpret_cast<const int*>(dp + oIds), mapCap, mapPts, mapDesc, K->invLevelSigma2, K->uRight, 1,
+                       static_cast<const unsigned long long*>(nullptr), -1, dBest, dBest + M);
+    MCHK(hipGetLastError());
+    int* hBest = reinterpret_cast<int*>(hp + oBest);
     MCHK(hipMemcpyAsync(hBest, dBest, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MCHK(hipStreamSynchronize(s));
     memcpy(bestIdxOut, hBest, (size_t)M * sizeof(int));

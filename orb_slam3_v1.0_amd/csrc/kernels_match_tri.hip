@@ -609,6 +609,7 @@ void keyframe_destroy(KeyFrameDev* K)
 {
     if (!K) return;
     if (K->block) (void)hipFree(K->block);
+    match_scratch_free(K->gridMem);  // the cell tables of keyframe_set_grid, if any
     delete K;
 }
 

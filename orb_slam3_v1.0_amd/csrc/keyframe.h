@@ -9,6 +9,7 @@
 #include <string>
 
 #include "match.h"
+#include "match_proj.h"
 
 namespace orbfe {
 
@@ -25,11 +26,30 @@ struct KeyFrameDev {
     const int* order = nullptr;      // features with a node, sorted by (node, index)
     const int* nodeList = nullptr;   // [G] distinct nodes, ascending
     const int* nodeOff = nullptr;    // [G + 1] ranges of `order`
+    // ---- what the projection searches into this key frame read (Fuse: KeyFrame::GetFeaturesInArea on mGrid,
+    //      src/KeyFrame.cc:790-833), built ONCE by keyframe_set_grid: the per-level cell tables of kernels_match_proj.hip
+    //      (storage order, cell-column starts, descriptors in storage order) plus mvInvLevelSigma2 and mvuRight ----
+    bool hasGrid = false;
+    MatchScratch gridMem;            // owns the tables (device arena)
+    proj::ProjArgs grid{};           // bound to gridMem + the key frame's own keypoints / descriptors / scale factors
+    const float* invLevelSigma2 = nullptr;  // [nLevels]
+    const float* uRight = nullptr;          // [n] or null (monocular)
 };
 
 int keyframe_create(int n, const orbfe_keypoint* kp, const uint8_t* desc, const int* nodeId, const uint8_t* stereo,
                     const float* sf, int nLevels, hipStream_t s, KeyFrameDev** out, std::string& err);
 void keyframe_destroy(KeyFrameDev* K);
+
+// mGrid of the key frame (grid geometry as orbfe_frame_view), mvInvLevelSigma2 (nLevels floats) and mvuRight (n floats or
+// null): one launch of the grid kernel, tables kept with the key frame.  Synchronises.
+int keyframe_set_grid(KeyFrameDev* K, hipStream_t s, int gridCols, int gridRows, float minX, float minY, float invW, float invH,
+                      const float* invLevelSigma2, const float* uRight, std::string& err);
+// the search part of ORBmatcher::Fuse(pKF, vpMapPoints, th) against a RESIDENT key frame (keyframe_set_grid done) with the map
+// points named by id out of a resident map: ids[i] >= 0 entry of the map, ~id (negative) = "!pMP || pMP->IsInKeyFrame(pKF)"
+// for this call (skipped), outside the map = no point.  Up: the ids and the frustum; down: (bestIdx, bestDist) per id.
+int fuse_search_keyframe_run(MatchScratch& m, hipStream_t s, const KeyFrameDev* K, int mapCap, const orbfe_world_point* mapPts,
+                             const uint8_t* mapDesc, int M, const int* ids, const orbfe_frustum* F, float th, int* bestIdxOut,
+                             int* bestDistOut, std::string& err);
 
 // SearchForTriangulation of key frame 1 against K neighbours in one launch: raw matches + rotation bins per (neighbour,
 // feature of key frame 1); the per-neighbour selection runs on the host (orbfe_triangulation_select)

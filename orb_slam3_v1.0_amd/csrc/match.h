@@ -33,6 +33,15 @@ int match_initialization_run(MatchScratch& m, hipStream_t s, const orbfe_frame_v
                              int windowSize, float nnRatio, int checkOrientation, int* matches12Out, int* nMatches,
                              std::string& err);
 
+// the same matcher inside a captured per-frame chain (orbfe_track_initialization): frame 1 = a resident initial frame (n1
+// keypoints, n0 of them on level 0, listed in index order in dList0), frame 2 = the fresh keypoints of the current frame on the
+// device (count in *dN2, <= cap); `scratch` = init_track_scratch_bytes(n1, n0, cap) bytes of device memory
+size_t init_track_scratch_bytes(int n1, int n0, int cap);
+int init_track_launch(hipStream_t s, int n1, int n0, const orbfe_keypoint* dKp1, const uint8_t* dDesc1, const int* dList0,
+                      const orbfe_keypoint* dKp2, const uint8_t* dDesc2, const int* dN2, int cap, int gridCols, int gridRows,
+                      float minX, float minY, float invW, float invH, int windowSize, float nnRatio, int checkOrientation,
+                      int* dMatches12, int* dNMatches, uint8_t* scratch, std::string& err);
+
 int match_bow_run(MatchScratch& m, hipStream_t s, int G, const int* kfOff, const int* kfIdx, const int* fOff,
                   const int* fIdx, int nKF, const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfHasMP,
                   int nF, const uint8_t* fDesc, const float* fAngle, int nLeft, float nnRatio, int checkOrientation,

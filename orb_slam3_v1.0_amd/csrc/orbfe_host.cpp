@@ -140,6 +140,24 @@ struct orbfe_handle {
     uint8_t* hRefOut = nullptr;
     int refCapFlags = 0;
     std::vector<RefGraph> refGraphs;
+    // orbfe_track_initialization: extract -> SearchForInitialization(resident initial frame, frame).  A graph holds the
+    // addresses of the initial frame it was captured for (named by its serial) and of these blocks.
+    struct IniKey {
+        int inPitch, gridCols, gridRows, window, checkOri;
+        float minX, minY, invW, invH, nnRatio;
+        unsigned long long frameSerial;
+    };
+    struct IniGraph {
+        IniKey key;
+        hipGraphExec_t exec;
+    };
+    uint8_t* dIniIn = nullptr;    // [image]
+    uint8_t* hIniIn = nullptr;
+    uint8_t* dIniOut = nullptr;   // [n, status, n_matches | per-level | keypoints | descriptors | matches12 (iniCapN1)] + matcher scratch
+    uint8_t* hIniOut = nullptr;
+    int iniCapN1 = -1;
+    size_t iniScratchBytes = 0;
+    std::vector<IniGraph> iniGraphs;
     std::mutex mu;
     std::string err;
     // objects that keep a pointer to this handle: orbfe_destroy releases their device memory and orphans them (h = null), so
@@ -237,6 +255,12 @@ void destroy_impl(orbfe_handle* h)
     match_scratch_free(h->trackMatch);
     for (auto& g : h->refGraphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : h->iniGraphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (h->dIniIn) (void)hipFree(h->dIniIn);
+    if (h->dIniOut) (void)hipFree(h->dIniOut);
+    if (h->hIniIn) (void)hipHostFree(h->hIniIn);
+    if (h->hIniOut) (void)hipHostFree(h->hIniOut);
     if (h->dRefIn) (void)hipFree(h->dRefIn);
     if (h->dRefOut) (void)hipFree(h->dRefOut);
     if (h->hRefIn) (void)hipHostFree(h->hRefIn);
@@ -2177,6 +2201,37 @@ void orbfe_keyframe_destroy(orbfe_keyframe* kf)
 
 int orbfe_keyframe_size(const orbfe_keyframe* kf) { return kf ? kf->k->n : 0; }
 
+int orbfe_keyframe_set_grid(orbfe_handle* h, orbfe_keyframe* kf, int grid_cols, int grid_rows, float min_x, float min_y,
+                            float grid_inv_w, float grid_inv_h, const float* inv_level_sigma2, const float* u_right)
+{
+    if (!h || !kf || kf->device != h->device || !inv_level_sigma2 || grid_cols < 1 || grid_rows < 1) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    const int rc = keyframe_set_grid(kf->k, h->stream, grid_cols, grid_rows, min_x, min_y, grid_inv_w, grid_inv_h, inv_level_sigma2,
+                                     u_right, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
+int orbfe_fuse_search_keyframe(orbfe_handle* h, const orbfe_keyframe* kf, const orbfe_map* map, int M, const int* ids,
+                               const orbfe_frustum* frustum, float th, int* best_idx_out, int* best_dist_out)
+{
+    if (!h || !kf || !map || kf->device != h->device || map->h != h || M < 0 || (M > 0 && (!ids || !best_idx_out || !best_dist_out)))
+        return ORBFE_ERR_INVALID_ARG;
+    const int rc0 = frustum_validate(frustum);
+    if (rc0 != ORBFE_OK) return rc0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string err;
+    MatchScope scope_(h, h->stream);  // also orders the call behind an orbfe_map_update of another stream's making
+    if (scope_.rc != ORBFE_OK) return scope_.rc;
+    const int rc = fuse_search_keyframe_run(h->match, h->stream, kf->k, map->cap, map->dPts, map->dDesc, M, ids, frustum, th,
+                                            best_idx_out, best_dist_out, err);
+    if (rc != ORBFE_OK) h->err = err;
+    return rc;
+}
+
 int orbfe_match_triangulation_batch(orbfe_handle* h, const orbfe_keyframe* kf1, const uint8_t* has_mp1, int K,
                                     const orbfe_keyframe* const* kf2, const uint8_t* const* has_mp2,
                                     const orbfe_tri_params* params, int* raw_match12, uint8_t* raw_bin)
@@ -2711,3 +2766,265 @@ extern "C" int orbfe_track_reference_keyframe(orbfe_handle* h, const uint8_t* gr
     return ORBFE_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// orbfe_track_initialization: extract -> SearchForInitialization(resident initial frame, frame) as one captured hipGraph
+// ---------------------------------------------------------------------------------------------
+struct orbfe_init_frame {
+    int device;
+    unsigned long long serial;  // names the frame in graph keys (an address could be reused after a destroy)
+    int n, n0;                  // keypoints, level-0 keypoints (the only ones SearchForInitialization walks, ORBmatcher.cc:346-347)
+    void* block;
+    const orbfe_keypoint* kp;
+    const uint8_t* desc;
+    const int* list0;           // level-0 keypoints in index order
+};
+static std::atomic<unsigned long long> g_initFrameSerial{1};
+
+extern "C" int orbfe_init_frame_create(orbfe_handle* h, int n, const orbfe_keypoint* kp, const uint8_t* desc, orbfe_init_frame** out)
+{
+    if (!h || !out || n < 0 || (n > 0 && (!kp || !desc))) return ORBFE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n >= (1 << 20)) return ORBFE_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int> list0;
+    for (int i = 0; i < n; i++)
+        if (kp[i].octave <= 0) list0.push_back(i);  // level1 > 0 -> continue (:346-347)
+    Carver c;
+    const size_t oKp = c.take((size_t)std::max(n, 1) * sizeof(orbfe_keypoint));
+    const size_t oDesc = c.take((size_t)std::max(n, 1) * ORBFE_DESC_BYTES);
+    const size_t oList = c.take((size_t)std::max(n, 1) * sizeof(int));  // n entries: the sequential matcher kernel rebuilds the list in place
+    std::vector<uint8_t> img(c.off, 0);
+    if (n) {
+        memcpy(&img[oKp], kp, (size_t)n * sizeof(orbfe_keypoint));
+        memcpy(&img[oDesc], desc, (size_t)n * ORBFE_DESC_BYTES);
+    }
+    if (!list0.empty()) memcpy(&img[oList], list0.data(), list0.size() * sizeof(int));
+    void* block = nullptr;
+    if (hipMalloc(&block, c.off) != hipSuccess) {
+        (void)hipGetLastError();
+        h->err = "orbfe_init_frame_create: allocation failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    if (copy_sync(block, img.data(), c.off, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(block);
+        h->err = "orbfe_init_frame_create: upload failed";
+        return ORBFE_ERR_HIP;
+    }
+    uint8_t* b = static_cast<uint8_t*>(block);
+    *out = new orbfe_init_frame{h->device, g_initFrameSerial.fetch_add(1), n, (int)list0.size(), block,
+                                reinterpret_cast<const orbfe_keypoint*>(b + oKp), b + oDesc, reinterpret_cast<const int*>(b + oList)};
+    return ORBFE_OK;
+}
+
+extern "C" void orbfe_init_frame_destroy(orbfe_init_frame* f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();  // (a replay that reads the block may still be running on some handle's stream)
+    if (f->block) (void)hipFree(f->block);
+    delete f;
+}
+
+extern "C" int orbfe_init_frame_size(const orbfe_init_frame* f) { return f ? f->n : 0; }
+
+namespace {
+
+struct IniLayout {
+    size_t inFrame, inBytes;
+    size_t oPer, oKp, oDesc, oMatch, outBytes /* what is downloaded */, oScratch, devBytes;
+};
+
+IniLayout ini_layout(const orbfe_handle* h, int capN1, size_t scratchBytes)
+{
+    IniLayout L{};
+    const size_t cap = (size_t)h->P.kpCapFrame;
+    L.inFrame = align_up((size_t)h->dInPitch * h->prm.image_height, 256);
+    L.inBytes = L.inFrame;
+    size_t off = 256;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.oPer = take((size_t)h->nLevels * sizeof(int));
+    L.oKp = take(cap * sizeof(orbfe_keypoint));
+    L.oDesc = take(cap * ORBFE_DESC_BYTES);
+    L.oMatch = take((size_t)std::max(capN1, 1) * sizeof(int));
+    L.outBytes = off;
+    L.oScratch = take(scratchBytes);
+    L.devBytes = off;
+    return L;
+}
+
+void ini_drop_graphs(orbfe_handle* h)
+{
+    for (auto& g : h->iniGraphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->iniGraphs.clear();
+}
+
+int ini_reserve(orbfe_handle* h, int n1, size_t scratchBytes)
+{
+    if (h->dIniIn && n1 <= h->iniCapN1 && scratchBytes <= h->iniScratchBytes) return ORBFE_OK;
+    ini_drop_graphs(h);
+    if (h->dIniIn) (void)hipFree(h->dIniIn);
+    if (h->dIniOut) (void)hipFree(h->dIniOut);
+    if (h->hIniIn) (void)hipHostFree(h->hIniIn);
+    if (h->hIniOut) (void)hipHostFree(h->hIniOut);
+    h->dIniIn = h->dIniOut = h->hIniIn = h->hIniOut = nullptr;
+    h->iniCapN1 = -1;
+    h->iniScratchBytes = 0;
+    const int capN1 = std::max(n1 + n1 / 2, h->P.kpCapFrame);  // the initial frame is a frame of this extractor: <= kpCapFrame keypoints
+    const size_t capScratch = std::max(scratchBytes + scratchBytes / 2, init_track_scratch_bytes(capN1, std::min(capN1, 1024), h->P.kpCapFrame));
+    const IniLayout L = ini_layout(h, capN1, capScratch);
+    if (hipMalloc(&h->dIniIn, L.inBytes) != hipSuccess || hipMalloc(&h->dIniOut, L.devBytes) != hipSuccess ||
+        hipHostMalloc(&h->hIniIn, L.inBytes) != hipSuccess || hipHostMalloc(&h->hIniOut, L.outBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        h->err = "orbfe_track_initialization: allocation of the staging blocks failed";
+        return ORBFE_ERR_OUT_OF_MEMORY;
+    }
+    h->iniCapN1 = capN1;
+    h->iniScratchBytes = capScratch;
+    return ORBFE_OK;
+}
+
+// the device side of one call, enqueued on s (directly, or under stream capture)
+int ini_enqueue(orbfe_handle* h, const IniLayout& L, int inPitch, const orbfe_init_frame* f1, const orbfe_track_params* tp, int window,
+                float nnRatio, int checkOri, hipStream_t s)
+{
+    const int cap = h->P.kpCapFrame;
+    int* dHead = reinterpret_cast<int*>(h->dIniOut);  // [n, status, n_matches]
+    orbfe_keypoint* dKp = reinterpret_cast<orbfe_keypoint*>(h->dIniOut + L.oKp);
+    int rc = extract_chain(h, h->dIniIn, L.inFrame, inPitch, 1, dKp, h->dIniOut + L.oDesc, dHead, reinterpret_cast<int*>(h->dIniOut + L.oPer),
+                           dHead + 1, s);
+    if (rc != ORBFE_OK) return rc;
+    std::string err;
+    rc = init_track_launch(s, f1->n, f1->n0, f1->kp, f1->desc, f1->list0, dKp, h->dIniOut + L.oDesc, dHead, cap, tp->grid_cols, tp->grid_rows,
+                           tp->min_x, tp->min_y, tp->grid_inv_w, tp->grid_inv_h, window, nnRatio, checkOri,
+                           reinterpret_cast<int*>(h->dIniOut + L.oMatch), dHead + 2, h->dIniOut + L.oScratch, err);
+    if (rc != ORBFE_OK) {
+        h->err = err;
+        return rc;
+    }
+    // [head | per-level | keypoints | descriptors | matches12 of THIS initial frame]: the block is laid out for iniCapN1 entries,
+    // the copy stops behind the n1 that exist
+    HIPCHK(h, hipMemcpyAsync(h->hIniOut, h->dIniOut, L.oMatch + (size_t)std::max(f1->n, 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    return ORBFE_OK;
+}
+
+}  // namespace
+
+extern "C" int orbfe_track_initialization(orbfe_handle* h, const uint8_t* gray, int pitch, const orbfe_init_frame* f1,
+                                          const orbfe_track_params* tp, int window_size, float nn_ratio, int check_orientation,
+                                          orbfe_keypoint* kp_out, uint8_t* desc_out, int* n_out, int* per_level, int* matches12_out,
+                                          int* n_matches)
+{
+    if (!h || !gray || !f1 || !tp || !kp_out || !desc_out || !n_out || !n_matches || window_size < 0 || (f1->n > 0 && !matches12_out))
+        return ORBFE_ERR_INVALID_ARG;
+    if (pitch < h->prm.image_width || pitch >= (1 << 24) || f1->device != h->device) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (tp->struct_size != (int)sizeof(orbfe_track_params)) {
+        h->err = "orbfe_track_params.struct_size does not match this library (rebuild the caller against include/orbfe.h)";
+        return ORBFE_ERR_INVALID_ARG;
+    }
+    if (tp->grid_cols < 1 || tp->grid_rows < 1) return ORBFE_ERR_INVALID_ARG;
+    if (h->P.kpCapFrame >= (1 << 20) || tp->grid_cols > 65535 || tp->grid_rows > 32767) return ORBFE_ERR_UNSUPPORTED;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int W = h->prm.image_width, H = h->prm.image_height, nL = h->nLevels;
+    int rc = ini_reserve(h, f1->n, init_track_scratch_bytes(f1->n, f1->n0, h->P.kpCapFrame));
+    if (rc != ORBFE_OK) return rc;
+    const IniLayout L = ini_layout(h, h->iniCapN1, h->iniScratchBytes);
+
+    // ---- upload (as orbfe_track_frame): pinned frames straight from the caller's buffer, pageable ones through the mirror ----
+    bool direct = pitch <= h->dInPitch && (pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(gray) & 3u) == 0;
+    if (direct) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, gray) != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            direct = false;
+        }
+    }
+    int inPitch;
+    if (direct) {
+        inPitch = pitch;
+        HIPCHK(h, hipMemcpyAsync(h->dIniIn, gray, (size_t)pitch * (H - 1) + (size_t)W, hipMemcpyHostToDevice, s));
+    } else {
+        if ((pitch & 3) == 0 && pitch <= h->dInPitch) {
+            inPitch = pitch;
+            memcpy(h->hIniIn, gray, (size_t)pitch * (H - 1) + (size_t)W);
+        } else {
+            inPitch = h->dInPitch;
+            for (int y = 0; y < H; y++) memcpy(h->hIniIn + (size_t)y * inPitch, gray + (size_t)y * pitch, (size_t)W);
+        }
+        HIPCHK(h, hipMemcpyAsync(h->dIniIn, h->hIniIn, (size_t)inPitch * (H - 1) + (size_t)W, hipMemcpyHostToDevice, s));
+    }
+
+    // ---- kernels + download: replay the graph of this (initial frame, pitch, parameters), capturing it first if needed ----
+    bool viaGraph = h->useGraph && !h->timing;
+    if (viaGraph) {
+        orbfe_handle::IniKey key;
+        memset(&key, 0, sizeof key);
+        key.inPitch = inPitch; key.gridCols = tp->grid_cols; key.gridRows = tp->grid_rows; key.window = window_size;
+        key.checkOri = check_orientation; key.minX = tp->min_x; key.minY = tp->min_y; key.invW = tp->grid_inv_w; key.invH = tp->grid_inv_h;
+        key.nnRatio = nn_ratio; key.frameSerial = f1->serial;
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : h->iniGraphs)
+            if (memcmp(&g.key, &key, sizeof key) == 0) exec = g.exec;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            {
+                CaptureStream cs;
+                rc = cs.begin() ? ini_enqueue(h, L, inPitch, f1, tp, window_size, nn_ratio, check_orientation, cs.s) : ORBFE_ERR_HIP;
+                graph = cs.end();
+            }
+            if (rc == ORBFE_OK && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!exec) {
+                graph_capture_failed(h);  // plain launches for this call
+                viaGraph = false;
+            } else {
+                graph_capture_succeeded(h);
+                if (h->iniGraphs.size() >= 8) ini_drop_graphs(h);  // initial frames come and go (:569-602): bounded cache
+                h->iniGraphs.push_back({key, exec});
+            }
+        }
+        if (viaGraph) {
+            rc = scratch_acquire(h, h->extractUsed, h->extractStream, h->evExtract, s);
+            if (rc != ORBFE_OK) return rc;
+            HIPCHK(h, hipGraphLaunch(exec, s));
+            rc = extract_scratch_release(h, s);
+            if (rc != ORBFE_OK) return rc;
+            h->lastGray = h->dIniIn;
+            h->lastStride = L.inFrame;
+            h->lastPitch = inPitch;
+            h->lastBatch = 1;
+        }
+    }
+    if (!viaGraph) {
+        rc = ini_enqueue(h, L, inPitch, f1, tp, window_size, nn_ratio, check_orientation, s);
+        if (rc != ORBFE_OK) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+
+    // ---- hand over ----
+    const int* head = reinterpret_cast<const int*>(h->hIniOut);
+    if (head[1]) {
+        char buf[112];
+        snprintf(buf, sizeof buf, "device guard flags 0x%x in orbfe_track_initialization", (unsigned)head[1]);
+        h->err = buf;
+        return ORBFE_ERR_INTERNAL;
+    }
+    const int n = head[0];
+    *n_out = n;
+    memcpy(kp_out, h->hIniOut + L.oKp, (size_t)n * sizeof(orbfe_keypoint));
+    memcpy(desc_out, h->hIniOut + L.oDesc, (size_t)n * ORBFE_DESC_BYTES);
+    if (per_level) memcpy(per_level, h->hIniOut + L.oPer, (size_t)nL * sizeof(int));
+    if (n > 0 && f1->n > 0) {
+        *n_matches = head[2];
+        memcpy(matches12_out, h->hIniOut + L.oMatch, (size_t)f1->n * sizeof(int));
+    } else {  // the reference returns early on either empty frame (vnMatches12 all -1)
+        *n_matches = 0;
+        for (int i = 0; i < f1->n; i++) matches12_out[i] = -1;
+    }
+    return ORBFE_OK;
+}

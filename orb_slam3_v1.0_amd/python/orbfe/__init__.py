@@ -119,7 +119,8 @@ SYMBOLS = [
     "orbfe_keyframe_create", "orbfe_keyframe_destroy", "orbfe_keyframe_size", "orbfe_match_triangulation_batch",
     "orbfe_triangulation_select", "orbfe_map_create", "orbfe_map_destroy", "orbfe_map_update", "orbfe_stream_enable_track",
     "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map", "orbfe_track_reference_keyframe", "orbfe_debug_graph_stats", "orbfe_set_graph_capture",
-    "orbfe_debug_clock_probe",
+    "orbfe_debug_clock_probe", "orbfe_keyframe_set_grid", "orbfe_fuse_search_keyframe",
+    "orbfe_init_frame_create", "orbfe_init_frame_destroy", "orbfe_init_frame_size", "orbfe_track_initialization",
 ]
 
 _lib = None
@@ -199,6 +200,11 @@ def lib():
     L.orbfe_track_frame.argtypes = [vp, vp, ci, C.POINTER(Frustum), C.POINTER(TrackParams), ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_track_frame_map.argtypes = [vp, vp, ci, C.POINTER(Frustum), C.POINTER(TrackParams), vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_track_reference_keyframe.argtypes = [vp, vp, ci, vp, ci, vp, vp, C.c_float, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orbfe_init_frame_create.argtypes = [vp, ci, vp, vp, C.POINTER(vp)]
+    L.orbfe_init_frame_destroy.argtypes = [vp]
+    L.orbfe_init_frame_destroy.restype = None
+    L.orbfe_init_frame_size.argtypes = [vp]
+    L.orbfe_track_initialization.argtypes = [vp, vp, ci, vp, C.POINTER(TrackParams), ci, cf, ci, vp, vp, vp, vp, vp, vp]
     L.orbfe_project_map_points.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp]
     L.orbfe_project_map_points_device.argtypes = [vp, C.POINTER(Frustum), ci, vp, vp, vp, vp]
     L.orbfe_fuse_search.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.POINTER(Frustum), cf, ci, vp, vp, vp, vp]
@@ -220,6 +226,8 @@ def lib():
     L.orbfe_keyframe_destroy.argtypes = [vp]
     L.orbfe_keyframe_destroy.restype = None
     L.orbfe_keyframe_size.argtypes = [vp]
+    L.orbfe_keyframe_set_grid.argtypes = [vp, vp, ci, ci, cf, cf, cf, cf, vp, vp]
+    L.orbfe_fuse_search_keyframe.argtypes = [vp, vp, vp, ci, vp, C.POINTER(Frustum), cf, vp, vp]
     L.orbfe_match_triangulation_batch.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
     L.orbfe_triangulation_select.argtypes = [ci, vp, vp, vp, ci, vp, vp]
     L.orbfe_distinctive_descriptors.argtypes = [vp, ci, vp, vp, vp, vp]
@@ -637,6 +645,18 @@ class ORBmatcher:
                                              _p(points), _p(mpDesc), _p(bi), _p(bd)), "orbfe_fuse_search")
         return bi[:M], bd[:M]
 
+    def Fuse_search_keyframe(self, kf, map_points, ids, frustum, th):
+        """orbfe_fuse_search_keyframe: the search part of Fuse against a RESIDENT KeyFrame (set_grid done) with the map points
+        named by id out of a resident MapPoints table (id >= 0; ~id = "!pMP || pMP->IsInKeyFrame(pKF)" for this call; outside
+        the map = no point) -> (bestIdx, bestDist) per id."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        M = len(ids)
+        bi = np.zeros(max(M, 1), np.int32)
+        bd = np.zeros(max(M, 1), np.int32)
+        self.e._chk(self.L.orbfe_fuse_search_keyframe(self.e.h, kf.h, map_points.h, M, _p(ids), C.byref(frustum), th, _p(bi), _p(bd)),
+                    "orbfe_fuse_search_keyframe")
+        return bi[:M], bd[:M]
+
     def Fuse_search_right(self, kf_left_view, nRight, invLevelSigma2, uRight, frustum, th, points, mpDesc):
         """Fuse(pKF, vpMapPoints, th, bRight = true) (src/ORBmatcher.cc:684-688,:820): kf_left_view describes the NLeft left
         features with desc = all NLeft + nRight rows of mDescriptors; frustum = right pose / mpCamera2; returned indices are
@@ -752,9 +772,41 @@ class KeyFrame:
         extractor._chk(self.L.orbfe_keyframe_create(extractor.h, self.n, _p(kp), _p(desc), _p(node), _p(st), _p(sf), len(sf),
                                                     C.byref(self.h)), "orbfe_keyframe_create")
 
+    def set_grid(self, gridCols, gridRows, minX, minY, maxX, maxY, invLevelSigma2, uRight=None):
+        """orbfe_keyframe_set_grid: mGrid's geometry (as make_frame_view derives it, src/Frame.cc:101-105), mvInvLevelSigma2 and
+        mvuRight -- the per-level cell tables are built once and stay with the key frame (Fuse_search_keyframe)."""
+        invw = float(np.float32(gridCols) / np.float32(np.float32(maxX) - np.float32(minX)))
+        invh = float(np.float32(gridRows) / np.float32(np.float32(maxY) - np.float32(minY)))
+        is2 = np.ascontiguousarray(invLevelSigma2, np.float32)
+        ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        assert ur is None or len(ur) == self.n
+        self.e._chk(self.L.orbfe_keyframe_set_grid(self.e.h, self.h, int(gridCols), int(gridRows), float(minX), float(minY), invw, invh,
+                                                   _p(is2), _p(ur)), "orbfe_keyframe_set_grid")
+
     def close(self):
         if getattr(self, "h", None):
             self.L.orbfe_keyframe_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class InitialFrame:
+    """mInitialFrame of Tracking::MonocularInitialization (src/Tracking.cc:569-586) resident in HBM (orbfe_init_frame_*): the
+    keypoints and descriptors every following frame is matched against while the map is being initialised."""
+
+    def __init__(self, extractor, kp, desc):
+        self.e, self.L = extractor, extractor.L
+        kp = np.ascontiguousarray(kp, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        assert len(kp) == len(desc)
+        self.n = len(kp)
+        self.h = C.c_void_p()
+        extractor._chk(self.L.orbfe_init_frame_create(extractor.h, self.n, _p(kp), _p(desc), C.byref(self.h)), "orbfe_init_frame_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_init_frame_destroy(self.h)
             self.h = None
 
     __del__ = close
@@ -850,6 +902,26 @@ class FrameTracker:
                                             _p(desc), C.byref(n), _p(per), _p(mps), _p(xr), _p(match), C.byref(nm)), "orbfe_track_frame_map")
         k = n.value
         return dict(kp=kp[:k], desc=desc[:k], per_level=per, mps=mps[:M], proj_xr=xr[:M], match=match[:k], nmatches=nm.value)
+
+    def TrackInitialization(self, im, initial_frame, windowSize=40, nnRatio=0.45, checkOrientation=True):
+        """orbfe_track_initialization: ExtractORB -> SearchForInitialization(mInitialFrame, mCurrentFrame, 40, 0.45, true)
+        (Tracking::MonocularInitialization, src/Tracking.cc:566-607) as one call against a resident InitialFrame ->
+        dict(kp, desc, per_level, matches12, nmatches); matches12[i1] = index in the current frame or -1."""
+        e = self.e
+        im = np.asarray(im)
+        assert im.dtype == np.uint8 and im.shape == (e.H, e.W) and im.strides[1] == 1
+        tp = TrackParams()
+        (tp.grid_cols, tp.grid_rows, tp.min_x, tp.min_y, tp.grid_inv_w, tp.grid_inv_h) = self.grid
+        kp = np.zeros(e.cap, KP_DTYPE)
+        desc = np.zeros((e.cap, 32), np.uint8)
+        per = np.zeros(e.nlevels, np.int32)
+        m12 = np.full(max(initial_frame.n, 1), -1, np.int32)
+        n, nm = C.c_int(), C.c_int()
+        e._chk(self.L.orbfe_track_initialization(e.h, _p(im), im.strides[0], initial_frame.h, C.byref(tp), int(windowSize), nnRatio,
+                                                 int(bool(checkOrientation)), _p(kp), _p(desc), C.byref(n), _p(per), _p(m12), C.byref(nm)),
+               "orbfe_track_initialization")
+        k = n.value
+        return dict(kp=kp[:k], desc=desc[:k], per_level=per, matches12=m12[:initial_frame.n], nmatches=nm.value)
 
     def TrackReferenceKeyFrame(self, im, vocab, levelsup, kf, kfHasMP, nnRatio=0.75, checkOrientation=True):
         """orbfe_track_reference_keyframe: ExtractORB -> the per-feature part of ComputeBoW -> SearchByBoW(reference key frame,

@@ -102,6 +102,17 @@ def main():
     row("orbfe_fuse_search", "ORBmatcher.cc:678-836", "N=%d M=%d th=3" % (n, M),
         lambda: m.Fuse_search(fv, inv_s2, None, Fp, 3.0, pts.view(orbfe.WP_DTYPE), fmpd),
         lambda: O.fuse_search(fvo, inv_s2, None, Fo, 3.0, pts, fmpd), eqp)
+    # the same search against a RESIDENT key frame with the map points named by id out of a resident map (SearchInNeighbors' shape)
+    kf_res_f = orbfe.KeyFrame(ex, kpp, desc, np.full(n, -1, np.int32), ex.mvScaleFactor)
+    kf_res_f.set_grid(64, 48, 0.0, 0.0, float(W), float(H), inv_s2, None)
+    mp_res_f = orbfe.MapPoints(ex, M)
+    st_f = pts.copy()
+    st_f["skip"] = 0
+    mp_res_f.update(np.arange(M), st_f.view(orbfe.WP_DTYPE), fmpd)
+    ids_f = np.where(pts["skip"] != 0, ~np.arange(M, dtype=np.int32), np.arange(M, dtype=np.int32)).astype(np.int32)
+    row("orbfe_fuse_search_keyframe", "LocalMapping.cc:764-860", "N=%d M=%d th=3, resident key frame + map" % (n, M),
+        lambda: m.Fuse_search_keyframe(kf_res_f, mp_res_f, ids_f, Fp, 3.0),
+        lambda: O.fuse_search(fvo, inv_s2, None, Fo, 3.0, pts, fmpd), eqp)
     row("orbfe_fuse_search_sim3", "ORBmatcher.cc:864-975", "N=%d M=%d th=4" % (n, M),
         lambda: m.Fuse_search_sim3(fv, Fp, 4.0, pts.view(orbfe.WP_DTYPE), fmpd),
         lambda: O.fuse_search_sim3(fvo, Fo, 4.0, pts, fmpd), eqp)
@@ -187,10 +198,12 @@ def main():
     ti = vs.spread_first_level(vs.make_tree(10, 6, seed=17, early_leaf_p=0.02), 18)
     voci = orbfe.ORBVocabulary(ex, ti["childOff"], ti["childIdx"], ti["nodeDesc"], ti["wordId"], ti["weight"], 6)
     tv = lambda d: O.vocab_transform(ti["childOff"], ti["childIdx"], ti["nodeDesc"], ti["wordId"], ti["weight"], 6, d, 4)
-    node_kf, node_f = tv(desc)[1], tv(descb)[1]
+    # mFeatVec holds a feature only when its word's weight is > 0 (TemplatedVocabulary.h:1168-1172): node -1 otherwise
+    (_, nk_, wk_), (_, nf_, wf_) = tv(desc), tv(descb)
+    node_kf, node_f = np.where(wk_ > 0, nk_, -1).astype(np.int32), np.where(wf_ > 0, nf_, -1).astype(np.int32)
     res_kf = orbfe.KeyFrame(ex, kpp, desc, node_kf, sf)
     has_kf = (np.random.default_rng(4).random(n) < 0.8).astype(np.uint8)
-    shared = sorted(set(node_kf.tolist()) & set(node_f.tolist()))
+    shared = sorted((set(node_kf.tolist()) & set(node_f.tolist())) - {-1})
     ko, ki, fo, fi = [0], [], [0], []
     for g in shared:
         ki += list(np.flatnonzero(node_kf == g)); fi += list(np.flatnonzero(node_f == g))
@@ -217,6 +230,26 @@ def main():
         ref_fused, ref_oracle, eq2)
     row("extract + bow_transform + match_bow", "Tracking.cc:825-835", "the same chain as three calls (CSR prebuilt)", ref_three_calls,
         ref_oracle, eq2)
+    # the chain of a frame during monocular initialisation (Tracking.cc:566-607): one submission against a resident initial
+    # frame, and the two calls it replaces (the reference's own parameters: window 40, ratio 0.45, orientation on)
+    ini = orbfe.InitialFrame(ex, kpp, desc)
+
+    def ini_two_calls():
+        k2, d2 = ex.extractFeatures(pinned)
+        f2 = orbfe.make_frame_view(k2, d2, 64, 48, 0.0, 0.0, float(W), float(H), ex.mvScaleFactor)
+        return m.SearchForInitialization(fv, f2, 40, 0.45, True)
+
+    def ini_oracle():
+        k2, d2, _ = eo.extract(frames[1])
+        f2 = O.make_frame_view(k2, d2, 64, 48, 0.0, 0.0, float(W), float(H), sf)
+        return O.search_for_initialization(fvo, f2, 40, 0.45, True)
+
+    def ini_fused():
+        r = trk.TrackInitialization(pinned, ini, 40, 0.45, True)
+        return r["nmatches"], r["matches12"]
+
+    row("orbfe_track_initialization", "Tracking.cc:566-607", "N=%d/%d window=40, one submission" % (n, len(kpb)), ini_fused, ini_oracle, eq2)
+    row("extract + match_initialization", "Tracking.cc:566-607", "the same chain as two calls", ini_two_calls, ini_oracle, eq2)
     if a.json:
         with open(a.json, "w") as f:
             json.dump(dict(host_cpus=os.cpu_count(), reps=a.reps, rows=rows), f, indent=1)
