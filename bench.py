@@ -808,6 +808,23 @@ def latency_block(cfg, device_index, frames, reps=200, tail_calls=5000):
     out["track_frame_equals_oracle"] = bool(n_o == got["nmatches"] and np.array_equal(match_o, got["match"]))
     out["track_frame_oracle_ms"] = _median_ms(oracle_chain, 10, 1)
     mp_res.close()
+    # the third per-frame chain of the tracking thread, while the map is being initialised (src/Tracking.cc:566-607): ExtractORB ->
+    # SearchForInitialization(mInitialFrame, mCurrentFrame, 40, 0.45, true) against an initial frame resident in HBM, ONE submission
+    ini = orbfe.InitialFrame(ex1, kp, desc)
+
+    def ini_chain():
+        it["i"] += 1
+        return trk.TrackInitialization(pinned[it["i"] % len(pinned)], ini, 40, 0.45, True)
+
+    out["track_initialization_ms"] = _median_ms(ini_chain, reps)
+    got_i = trk.TrackInitialization(pageable[1], ini, 40, 0.45, True)
+    kp_o1, desc_o1, _ = ref.extract(pageable[1])
+    n_i, m12_i = O.search_for_initialization(fvo, O.make_frame_view(kp_o1, desc_o1, GRID[0], GRID[1], 0.0, 0.0, float(W), float(H), ref.scaleFactors),
+                                             40, 0.45, True)
+    out["track_initialization_matches"] = int(got_i["nmatches"])
+    out["track_initialization_equals_oracle"] = bool(got_i["kp"].tobytes() == kp_o1.tobytes() and n_i == got_i["nmatches"] and
+                                                     np.array_equal(m12_i, got_i["matches12"]))
+    ini.close()
     if tail_calls > 0:
         # ---- tail latency of the two per-frame chains (src/Tracking.cc:152-173,925-930 / :825-835), alone and beside the mapping
         #      thread (src/LocalMapping.cc:66-110) on its own handle ----
@@ -858,7 +875,8 @@ def latency_block(cfg, device_index, frames, reps=200, tail_calls=5000):
     out["what"] = ("one %dx%d host frame per call through orbfe_extract (one captured hipGraph: H2D, kernels, D2H, sync); "
                    "orbfe_match_projection with %d map points, host pointers; three_calls = orbfe_extract + orbfe_project_map_points + "
                    "orbfe_match_projection back to back (three host synchronisations), track_frame = the same chain through "
-                   "orbfe_track_frame (one graph, one synchronisation); orbfe_prepare_and_extract %dx%d BGR -> %dx%d; "
+                   "orbfe_track_frame (one graph, one synchronisation); track_initialization = orbfe_track_initialization (extract + "
+                   "SearchForInitialization against a resident initial frame, one graph); orbfe_prepare_and_extract %dx%d BGR -> %dx%d; "
                    "`*_oracle_ms` = the single-thread C oracle on the same call" % (W, H, N_MAP_POINTS, SW, SH, DW, DH))
     prep.close()
     return out

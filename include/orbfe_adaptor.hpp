@@ -589,8 +589,95 @@ public:
     ResidentKeyFrame& operator=(const ResidentKeyFrame&) = delete;
     const orbfe_keyframe* get() const { return kf_; }
 
+    // mGrid of the key frame (src/KeyFrame.cc:33-80 copies the geometry from the Frame), mvInvLevelSigma2 and mvuRight: what the
+    // projection searches INTO this key frame read.  Call it once, right after the constructor; KeyFrameMatcher::FuseResident
+    // needs it.  `KF` needs mnGridCols, mnGridRows, mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv.
+    template <class KeyFramePtr>
+    void SetGrid(orbfe_handle* h, KeyFramePtr pKF)
+    {
+        orbfe_detail::check(orbfe_keyframe_set_grid(h, kf_, pKF->mnGridCols, pKF->mnGridRows, pKF->mnMinX, pKF->mnMinY,
+                                                    pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, pKF->mvInvLevelSigma2.data(),
+                                                    pKF->mvuRight.empty() ? nullptr : pKF->mvuRight.data()), h, "orbfe_keyframe_set_grid");
+    }
+
 private:
     orbfe_keyframe* kf_ = nullptr;
+};
+
+// Map points resident on the GPU (orbfe_map_*): what isInFrustum, SearchByProjection and Fuse read from a MapPoint, indexed by
+// an id the caller assigns (MapPoint::mnId modulo the capacity, or a slot from a free list).  Update(pMP, id) where the
+// reference changes a point: the constructors, SetWorldPos, UpdateNormalAndDepth (mfMin/MaxDistance),
+// ComputeDistinctiveDescriptors, SetBadFlag / Replace (src/MapPoint.cc).
+class ResidentMap {
+public:
+    ResidentMap(orbfe_handle* h, int capacity) : h_(h)
+    {
+        orbfe_detail::check(orbfe_map_create(h, capacity, &m_), h, "orbfe_map_create");
+    }
+    ~ResidentMap() { orbfe_map_destroy(m_); }
+    ResidentMap(const ResidentMap&) = delete;
+    ResidentMap& operator=(const ResidentMap&) = delete;
+    template <class MapPointPtr, class DescOfMP>
+    void Update(const std::vector<MapPointPtr>& vpMPs, const std::vector<int>& ids, DescOfMP descOfMP)
+    {
+        const int n = (int)vpMPs.size();
+        std::vector<orbfe_world_point> pts(n > 0 ? n : 1);
+        std::vector<uint8_t> d((size_t)(n > 0 ? n : 1) * 32);
+        for (int i = 0; i < n; i++) {
+            const auto& pMP = vpMPs[i];
+            const auto P = pMP->GetWorldPos();
+            pts[i] = orbfe_world_point{P[0], P[1], P[2], pMP->mfMinDistance, pMP->mfMaxDistance, pMP->isBad() ? 1 : 0, pMP->Observations(), 0};
+            std::memcpy(&d[(size_t)i * 32], descOfMP(pMP), 32);
+        }
+        orbfe_detail::check(orbfe_map_update(h_, m_, n, ids.data(), pts.data(), d.data()), h_, "orbfe_map_update");
+    }
+    const orbfe_map* get() const { return m_; }
+
+private:
+    orbfe_handle* h_;
+    orbfe_map* m_ = nullptr;
+};
+
+// ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:678-851) for LocalMapping::SearchInNeighbors
+// (src/LocalMapping.cc:764-860, calls at :822,:852) on RESIDENT data: the target key frame is a ResidentKeyFrame with SetGrid
+// done, the map points are entries of a ResidentMap (ids[i] = the entry of vpMapPoints[i]); a frustum and 4 bytes per map point
+// go up instead of the key frame and 64 bytes per point.  The replay loop is KeyFrameMatcher::Fuse's: :699-849 in list order
+// on the live graph.  The caller pushes what the loop changed (Replace: descriptor / observations of the surviving point) to
+// the ResidentMap before the next neighbour's call, as it would call ComputeDistinctiveDescriptors in the reference (:836-848).
+struct ResidentFuse {
+    template <class KeyFramePtr, class MapPointPtr>
+    static int Fuse(orbfe_handle* h, KeyFramePtr pKF, const ResidentKeyFrame& resident, const ResidentMap& map,
+                    const std::vector<MapPointPtr>& vpMapPoints, const std::vector<int>& ids, const float th,
+                    const orbfe_frustum& frustum)
+    {
+        const int M = (int)vpMapPoints.size();
+        std::vector<int> call(M > 0 ? M : 1), bestIdx(M > 0 ? M : 1), bestDist(M > 0 ? M : 1);
+        for (int i = 0; i < M; i++) {
+            const auto& pMP = vpMapPoints[i];
+            // "!pMP || pMP->IsInKeyFrame(pKF)" travels with the id (~id); isBad() is the resident entry's own flag (:706-721)
+            call[i] = (!pMP || pMP->IsInKeyFrame(pKF)) ? ~ids[i] : ids[i];
+        }
+        orbfe_detail::check(orbfe_fuse_search_keyframe(h, resident.get(), map.get(), M, call.data(), &frustum, th, bestIdx.data(),
+                                                       bestDist.data()), h, "orbfe_fuse_search_keyframe");
+        int nFused = 0;
+        for (int i = 0; i < M; i++) {
+            const auto& pMP = vpMapPoints[i];
+            if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;  // :701-720, re-evaluated in order
+            if (bestDist[i] > ORBFE_TH_LOW) continue;                       // :829
+            auto pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx[i]);
+                pKF->AddMapPoint(pMP, bestIdx[i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
 };
 
 // The SearchForTriangulation loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:455-488) with ONE GPU launch for
@@ -948,6 +1035,65 @@ struct ReferenceKeyFrameTracker {
             if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];  // src/ORBmatcher.cc:241
         return nmatches;
     }
+};
+
+// The tracking thread's chain of a frame while the map is being initialised, as ONE submission (orbfe_track_initialization):
+// what Tracking::GrabImageMonocular + Tracking::MonocularInitialization do up to ReconstructWithTwoViews -- Frame::Frame ->
+// ExtractORB (src/Frame.cc:178-189), ORBmatcher::SearchForInitialization(mInitialFrame, mCurrentFrame, 40, 0.45, true)
+// (src/Tracking.cc:603-607).  Seed(F) where the reference sets mInitialFrame = mCurrentFrame (:569-586) -- the frame's
+// keypoints and descriptors go to the GPU once; ExtractAndSearch(...) for every following frame; Reset() where the reference
+// clears mbReadyToInitializate (:588-602).  The thresholds around the calls (FEAT_INIT_COUNT, the 2 s time-out) stay in
+// Tracking.cc.
+class InitializationTracker {
+public:
+    explicit InitializationTracker(ORBextractor& extractor) : ex_(extractor) {}
+    ~InitializationTracker() { orbfe_init_frame_destroy(f1_); }
+    InitializationTracker(const InitializationTracker&) = delete;
+    InitializationTracker& operator=(const InitializationTracker&) = delete;
+    bool Ready() const { return f1_ != nullptr; }
+    void Reset()
+    {
+        orbfe_init_frame_destroy(f1_);
+        f1_ = nullptr;
+    }
+    template <class FramePtr, class DescOf>
+    void Seed(FramePtr F, DescOf descOf)
+    {
+        Reset();
+        orbfe_detail::check(orbfe_init_frame_create(ex_.handle(), (int)F->mvKeysUn->size(),
+                                                    reinterpret_cast<const orbfe_keypoint*>(F->mvKeysUn->data()), descOf(F), &f1_),
+                            ex_.handle(), "orbfe_init_frame_create");
+    }
+    // -> {nmatches, vnMatches12} as SearchForInitialization; F receives the fresh keypoints and descriptors (setDesc(F, rows, n));
+    // nmatches == -1 when the frame has no keypoints (the reference returns before Track(), src/Tracking.cc:158-159)
+    template <class FramePtr, class SetFrameDesc>
+    std::pair<int, std::vector<int>> ExtractAndSearch(const GrayImageView& im, FramePtr F, SetFrameDesc setDesc, int windowSize = 40,
+                                                      float nnRatio = 0.45f, bool checkOrientation = true)
+    {
+        orbfe_handle* h = ex_.handle();
+        const int cap = ex_.maxKeypoints(), n1 = orbfe_init_frame_size(f1_);
+        auto keys = std::make_shared<std::vector<KeyPoint>>(cap);
+        std::vector<uint8_t> desc((size_t)cap * ORBFE_DESC_BYTES);
+        std::vector<int> m12(n1 > 0 ? n1 : 1, -1);
+        orbfe_track_params tp = ORBFE_TRACK_PARAMS_INIT;
+        tp.grid_cols = F->getFrameGridCols(); tp.grid_rows = F->getFrameGridRows();
+        tp.min_x = F->mnMinX; tp.min_y = F->mnMinY;
+        tp.grid_inv_w = F->mfGridElementWidthInv; tp.grid_inv_h = F->mfGridElementHeightInv;
+        int n = 0, nmatches = 0;
+        orbfe_detail::check(orbfe_track_initialization(h, im.data, im.pitch, f1_, &tp, windowSize, nnRatio, checkOrientation ? 1 : 0,
+                                                       reinterpret_cast<orbfe_keypoint*>(keys->data()), desc.data(), &n, nullptr, m12.data(),
+                                                       &nmatches), h, "orbfe_track_initialization");
+        keys->resize(n);
+        F->mNumKeypoints = n;
+        F->mvKeysUn = keys;
+        setDesc(F, desc.data(), n);
+        m12.resize(n1);
+        return {n == 0 ? -1 : nmatches, std::move(m12)};
+    }
+
+private:
+    ORBextractor& ex_;
+    orbfe_init_frame* f1_ = nullptr;
 };
 
 }  // namespace ORB_SLAM3

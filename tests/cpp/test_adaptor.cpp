@@ -55,6 +55,8 @@ struct KeyFrame {
     std::map<unsigned, std::vector<unsigned>> mFeatVec;
     std::vector<std::shared_ptr<MapPoint3D>> mvpMapPoints;
     std::vector<float> mvuRight, mvScaleFactors, mvInvLevelSigma2;
+    int mnGridCols = 64, mnGridRows = 48;  // src/KeyFrame.cc:45 copies the grid geometry from the Frame
+    float mnMinX = 0, mnMinY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
     std::shared_ptr<MapPoint3D> GetMapPoint(size_t i) const { return mvpMapPoints[i]; }
     void AddMapPoint(const std::shared_ptr<MapPoint3D>& mp, size_t i) { mvpMapPoints[i] = mp; }
     std::vector<std::shared_ptr<MapPoint3D>> GetMapPointMatches() const { return mvpMapPoints; }
@@ -340,6 +342,51 @@ int main(int argc, char** argv)
         const int nf = KeyFrameMatcher::Fuse(ex.handle(), kf, mpts, 3.0f, fr, kv, 0,
                                              [](const std::shared_ptr<MapPoint3D>& m) { return m->desc; });
         std::printf("triangulation n=%d self=%zu fuse=%d of %zu\n", nt, self, nf, mpts.size());
+        {   // the same Fuse on RESIDENT data (LocalMapping::SearchInNeighbors' shape): fresh copies of the map points in a
+            // ResidentMap, the key frame with its grid tables on the GPU; ids and a frustum go up, nothing else
+            auto kfq = std::make_shared<KeyFrame>(*kf);
+            kfq->mvpMapPoints.assign(n, nullptr);
+            kfq->mfGridElementWidthInv = kv.grid_inv_w;
+            kfq->mfGridElementHeightInv = kv.grid_inv_h;
+            std::vector<std::shared_ptr<MapPoint3D>> fresh;
+            for (auto& m : mpts) {
+                auto c = std::make_shared<MapPoint3D>(*m);
+                c->inKF.clear(); c->bad = false; c->obs = 1;
+                fresh.push_back(c);
+            }
+            ResidentKeyFrame rq(ex.handle(), kfq, [](const std::shared_ptr<KeyFrame>& k) { return k->mDescriptors.data(); });
+            rq.SetGrid(ex.handle(), kfq);
+            ResidentMap rmap(ex.handle(), (int)fresh.size() + 8);
+            std::vector<int> ids(fresh.size());
+            for (size_t i = 0; i < ids.size(); i++) ids[i] = (int)i + 3;
+            rmap.Update(fresh, ids, [](const std::shared_ptr<MapPoint3D>& m) { return (const uint8_t*)m->desc; });
+            const int nfr2 = ResidentFuse::Fuse(ex.handle(), kfq, rq, rmap, fresh, ids, 3.0f, fr);
+            int sameSlots = 0;
+            for (int i = 0; i < n; i++) sameSlots += (kfq->mvpMapPoints[i] != nullptr) == (kf->mvpMapPoints[i] != nullptr);
+            std::printf("fuse_resident n=%d same_as_host_pointer_fuse=%d slots_equal=%d\n", nfr2, (int)(nfr2 == nf), (int)(sameSlots == n));
+        }
+        {   // the chain of a frame during monocular initialisation: the frame's own features as mInitialFrame
+            InitializationTracker ini(ex);
+            auto F1 = std::make_shared<Frame>();
+            F1->mvKeysUn = keys;
+            F1->mDescriptors = desc;
+            F1->mvScaleFactors = ex.GetScaleFactors();
+            F1->mfGridElementWidthInv = (float)F1->cols / (float)W;
+            F1->mfGridElementHeightInv = (float)F1->rows / (float)H;
+            ini.Seed(F1, [](const std::shared_ptr<Frame>& f) { return f->mDescriptors.data(); });
+            auto F2 = std::make_shared<Frame>();
+            F2->mfGridElementWidthInv = (float)F2->cols / (float)W;
+            F2->mfGridElementHeightInv = (float)F2->rows / (float)H;
+            auto [nIni, m12] = ini.ExtractAndSearch(GrayImageView{img.data(), W}, F2,
+                                                    [](const std::shared_ptr<Frame>& f, const uint8_t* rows, int k) { f->mDescriptors.assign(rows, rows + (size_t)k * 32); });
+            const auto two = ORBmatcher::SearchForInitialization(ex.handle(), F1, F, 40, 0.45f, true,
+                                                                 [](const std::shared_ptr<Frame>& f) { return f->mDescriptors.data(); });
+            int self0 = 0;
+            for (size_t i = 0; i < m12.size(); i++) self0 += m12[i] == (int)i;
+            std::printf("track_initialization n=%d same_as_two_calls=%d self=%d keypoints=%d\n", nIni, (int)(nIni == two.first && m12 == two.second),
+                        self0, F2->mNumKeypoints);
+            ini.Reset();
+        }
         {   // Fuse(..., bRight = true) on a two-camera key frame whose right features are copies of the left ones seen
             // from the same pose: the same map points fuse, with indices shifted by NLeft (:820)
             auto kfr = std::make_shared<KeyFrame>(*kf);

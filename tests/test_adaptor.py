@@ -147,6 +147,10 @@ def test_adaptor_matches_oracle(built, tmp_path):
     mt = re.search(r"triangulation n=(\d+) self=(\d+) fuse=(\d+) of (\d+)", stdout)
     assert mt and int(mt.group(1)) == nt and int(mt.group(2)) == int((m12 == np.arange(n_kp)).sum())
     assert int(mt.group(3)) > int(mt.group(4)) // 2  # most on-keypoint map points fuse
+    mq = re.search(r"fuse_resident n=(\d+) same_as_host_pointer_fuse=1 slots_equal=1", stdout)  # resident key frame + resident map
+    assert mq and int(mq.group(1)) == int(mt.group(3)), stdout
+    mi = re.search(r"track_initialization n=(\d+) same_as_two_calls=1 self=(\d+) keypoints=(\d+)", stdout)  # one submission == extract + match
+    assert mi and int(mi.group(1)) > 100 and int(mi.group(2)) >= 0.9 * int(mi.group(1)) and int(mi.group(3)) == n_kp, stdout
     mr = re.search(r"fuse_right n=(\d+) shifted=(\d+) left=(\d+)", stdout)   # bRight: same matches, indices + NLeft
     assert mr and int(mr.group(1)) == int(mt.group(3)) and int(mr.group(2)) > 0 and int(mr.group(3)) == 0
     mb = re.search(r"tri_batch first=(\d+) same_first=(\d+) dropped=(\d+) after=(\d+) seq_after=(\d+) same_after=(\d+)", stdout)

@@ -47,6 +47,7 @@ def test_default_line_has_the_contracted_fields(built):
     assert lat["track_frame_equals_oracle"] is True and lat["track_frame_matches"] > 100
     assert lat["track_frame_map_ms"] > 0 and lat["track_frame_map_equals_track_frame"] is True
     assert lat["track_frame_ms"] < lat["track_frame_oracle_ms"]
+    assert lat["track_initialization_ms"] > 0 and lat["track_initialization_equals_oracle"] is True and lat["track_initialization_matches"] > 50
     cfg = d["config"]
     assert cfg["frames_per_step"] == 48 and cfg["gather"] == "none" and cfg["gather_bytes_per_step"] == 0 and "workload" in cfg
     assert d["value_host_io"] > 0 and d["value_host_io_pageable"] > 0 and d["value_host_io_match"] > 0
