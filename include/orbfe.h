@@ -720,6 +720,12 @@ const char *orbfe_status_string(int status);
  * about 0.04 ms more per single-frame call) or make its first call of every shape before those threads start.  The
  * library itself never uses the NULL stream. */
 int orbfe_set_graph_capture(orbfe_handle *h, int enable);
+/* Priority of the handle's own HIP stream (the one every host-pointer entry point and every `stream == NULL` call runs on).
+ * The reference runs tracking and local mapping on two threads (src/System.cc); with one handle each, high = 1 on the tracking
+ * thread's handle lets its kernels be dispatched ahead of the mapping thread's whenever both have work queued (running waves
+ * are not pre-empted).  The stream is re-created: call it while the handle is idle (nothing submitted and not yet collected),
+ * typically right after orbfe_create.  high = 0 selects the lowest priority of the device's range. */
+int orbfe_set_stream_priority(orbfe_handle *h, int high);
 /* diagnostics: graphs this handle has captured so far, and captures that failed (e.g. invalidated by another thread's NULL-stream
  * call: the affected call ran on plain launches, its result is unaffected; after 8 failures IN A ROW a handle stops capturing
  * until orbfe_set_graph_capture(h, 1)) */

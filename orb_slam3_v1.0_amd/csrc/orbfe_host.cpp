@@ -1868,6 +1868,28 @@ int orbfe_set_graph_capture(orbfe_handle* h, int enable)
     return ORBFE_OK;
 }
 
+int orbfe_set_stream_priority(orbfe_handle* h, int high)
+{
+    if (!h) return ORBFE_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int least = 0, greatest = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));  // numerically lower = higher priority
+    hipStream_t ns = nullptr;
+    HIPCHK(h, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, high ? greatest : least));
+    // the handle must be idle: everything it enqueued has finished before the stream goes away
+    if (hipStreamSynchronize(h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(ns);
+        return ORBFE_ERR_HIP;
+    }
+    (void)hipStreamDestroy(h->stream);
+    h->stream = ns;
+    h->extractUsed = h->matchUsed = false;  // the hand-over events belonged to work that is complete
+    h->extractStream = h->matchStream = nullptr;
+    return ORBFE_OK;
+}
+
 int orbfe_debug_clock_probe(orbfe_handle* h, int spin_us, unsigned long long* d_out, void* stream)
 {
     if (!h || !d_out || spin_us < 1 || spin_us > 100000) return ORBFE_ERR_INVALID_ARG;

@@ -121,6 +121,7 @@ SYMBOLS = [
     "orbfe_stream_submit_track", "orbfe_stream_collect_track", "orbfe_track_frame_map", "orbfe_track_reference_keyframe", "orbfe_debug_graph_stats", "orbfe_set_graph_capture",
     "orbfe_debug_clock_probe", "orbfe_keyframe_set_grid", "orbfe_fuse_search_keyframe",
     "orbfe_init_frame_create", "orbfe_init_frame_destroy", "orbfe_init_frame_size", "orbfe_track_initialization",
+    "orbfe_set_stream_priority",
 ]
 
 _lib = None
@@ -168,6 +169,7 @@ def lib():
     L.orbfe_get_device_status.argtypes = [vp, vp]
     L.orbfe_debug_graph_stats.argtypes = [vp, vp, vp]
     L.orbfe_set_graph_capture.argtypes = [vp, ci]
+    L.orbfe_set_stream_priority.argtypes = [vp, ci]
     L.orbfe_debug_clock_probe.argtypes = [vp, ci, vp, vp]
     L.orbfe_stream_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
     L.orbfe_stream_destroy.argtypes = [vp]
@@ -369,6 +371,10 @@ class ORBextractor:
 
     def set_graph_capture(self, on):
         self._chk(self.L.orbfe_set_graph_capture(self.h, int(bool(on))), "orbfe_set_graph_capture")
+
+    def set_stream_priority(self, high):
+        """orbfe_set_stream_priority: the handle's own stream at the device's highest (True) / lowest (False) priority"""
+        self._chk(self.L.orbfe_set_stream_priority(self.h, int(bool(high))), "orbfe_set_stream_priority")
 
     def graph_stats(self):
         """(graphs captured, captures that failed and fell back to plain launches) of this handle"""

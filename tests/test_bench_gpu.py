@@ -65,7 +65,7 @@ def test_default_line_has_the_contracted_fields(built):
     assert clk["probes"] >= 32 and 100 < clk["min"] <= clk["mean"] <= clk["max"] < 2600, clk  # MI355X: 2400 MHz max clock
     assert 0.5 < su["headline_over_sustained"] < 2.0
     tail = lat["tail"]
-    for mode in ("alone", "loaded"):
+    for mode in ("alone", "loaded", "loaded_high_priority"):
         for k in ("track_frame", "track_reference_keyframe"):
             t = tail[mode][k]
             assert t["calls"] == 200 and 0 < t["p50"] <= t["p99"] <= t["max"], (mode, k, t)

@@ -190,3 +190,36 @@ def test_a_successful_capture_resets_the_failure_count(built):
     ex.set_graph_capture(True)
     b = ex.extractFeatures(img)
     assert a[0].tobytes() == b[0].tobytes() and ex.graph_stats() == (1, 0)
+
+
+def test_stream_priority_switch_keeps_results_and_graphs(built):
+    """orbfe_set_stream_priority re-creates the handle's stream: calls before and after it return the same bytes, the captured
+    graphs are replayed on the new stream, and a ring created before the switch keeps working (it launches on the handle's
+    stream of the moment)."""
+    import orbfe
+    from orbfe import synth
+    ex = orbfe.ORBextractor(*ARGS, device=0, max_batch=2)
+    frames = np.stack(list(synth.stream(W, H, 2, index0=70)))
+    trk = orbfe.FrameTracker(ex, 64, 48, 0.0, 0.0, float(W), float(H))
+    kp0, desc0 = ex.extractFeatures(frames[0])
+    Fp = orbfe.Frustum()
+    v = FS.fill_frustum(Fp, PN, W=float(W), H=float(H), seed=21)
+    pts, mpd = FS.world_points_on_keypoints(kp0.view(O.KP_DTYPE), desc0, v, 800, np.random.default_rng(1), 8)
+    pts = pts.view(orbfe.WP_DTYPE)
+    st = ex.stream(slots=2, slot_frames=2)
+    before = trk.TrackFrame(frames[1], Fp, pts, mpd, 20.0, 0.85)
+    st.submit(frames)
+    r0 = st.collect()
+    c0 = ex.graph_stats()[0]
+    for high in (True, False, True):
+        ex.set_stream_priority(high)
+        after = trk.TrackFrame(frames[1], Fp, pts, mpd, 20.0, 0.85)
+        for key in ("kp", "desc", "match"):
+            assert after[key].tobytes() == before[key].tobytes(), key
+        kp1, desc1 = ex.extractFeatures(frames[0])
+        assert kp1.tobytes() == kp0.tobytes() and np.array_equal(desc1, desc0)
+        st.submit(frames)
+        r1 = st.collect()
+        assert all(a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) for a, b in zip(r0, r1))
+    assert ex.graph_stats() == (c0, 0)  # no re-capture: the graphs do not depend on the stream they are launched on
+    st.close()
