@@ -59,3 +59,16 @@ def test_random_reference_keyframe_chains_exact(built):
     rng = np.random.default_rng(8)
     tot = [FR.one(rng, k) for k in range(14)]
     assert sum(m for _, m in tot) > 500
+
+
+@pytest.mark.gpu
+def test_random_initialisation_chains_and_resident_fuse_searches_exact(built):
+    """tests/tools/fuzz_new_chains.py: orbfe_track_initialization on random geometries, image classes, grids, initial frames
+    (previous frame / same image / another scene; shuffled, thinned, upper levels only, empty), windows, ratios; and
+    orbfe_fuse_search_keyframe on random key frames, grids, radii, mono / stereo / KannalaBrandt8, map sizes 1 ... 5000 with the
+    skip pattern travelling in the ids; every result against the oracle."""
+    import fuzz_new_chains as FN
+    rng = np.random.default_rng(10)
+    ini = [FN.one_init(rng, k) for k in range(14)]
+    fus = [FN.one_fuse(rng, k) for k in range(10)]
+    assert sum(t[1] for t in ini) > 300 and sum(t[1] for t in fus) > 500
