@@ -61,6 +61,7 @@ def test_default_line_has_the_contracted_fields(built):
     assert su["steps"] >= 200 and su["seconds"] >= 0.5 and su["value"] > 1000
     ms = su["ms_per_step"]
     assert 0 < ms["min"] <= ms["p50"] <= ms["p99"] <= ms["max"] and su["first_100_steps_value"] > 0 and su["last_100_steps_value"] > 0
+    assert 0 < ms["window8"]["p50"] <= ms["window8"]["p99"] <= ms["window8"]["max"] <= ms["max"] and ms["max_after_first_step"] <= ms["max"]
     clk = su["sclk_mhz"]
     assert clk["probes"] >= 32 and 100 < clk["min"] <= clk["mean"] <= clk["max"] < 2600, clk  # MI355X: 2400 MHz max clock
     assert 0.5 < su["headline_over_sustained"] < 2.0
