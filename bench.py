@@ -1016,7 +1016,11 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:  # --force-gather outside a launcher (one rank): a free port, not a fixed one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != a.gpus:  # n_gpus of the result line is the group that ran, never the flag
             raise SystemExit("--gpus %d but the RCCL group has %d ranks" % (a.gpus, dist.get_world_size()))
