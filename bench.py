@@ -424,6 +424,28 @@ def host_io_match_rate(ex, frames, slot_frames, rounds):
     return best, stats["matches"] / max(1, stats["frames"])
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """From here on file descriptor 1 of this process is the RESULT channel only: libraries that print to the C-level stdout (RCCL
+    writes its version banner there when the first communicator is made) are sent to stderr, the JSON line goes out through a
+    duplicate of the original descriptor (emit_line).  The driver reads ONE JSON line from stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        print(text, flush=True)
+    else:
+        os.write(_RESULT_FD, (text + "\n").encode())
+
+
 def _pct(v, q):
     return float(np.percentile(np.asarray(v, np.float64), q))
 
@@ -928,12 +950,12 @@ def launcher_selftest(a, rank, world):
     gv = r.verify_gather()  # this rank's slots of the gathered arrays == what it packed; the same bytes on every rank
     if rank == 0:
         counts = r.g_cnt.view(world, B, 2).tolist() if mode == "counts" else None
-        print(json.dumps({"metric": "selftest", "value": 0.0, "unit": "none", "n_gpus": dist.get_world_size(), "steps": a.steps,
+        emit_line(json.dumps({"metric": "selftest", "value": 0.0, "unit": "none", "n_gpus": dist.get_world_size(), "steps": a.steps,
                           "gather_verified": None if gv is None else {"mismatching_slots_all_ranks": gv[0], "identical_on_all_ranks": gv[1],
                                                                        "ok": gv[0] == 0 and gv[1]},
                           "warmup": a.warmup, "data": "stub", "config": {"workload": "launcher self-test (no device work)",
                                                                           "gather": mode, "gather_bytes_per_step": r.gather_bytes_per_step()},
-                          "gathered_counts": counts}), flush=True)
+                          "gathered_counts": counts}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -1000,6 +1022,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    claim_stdout()  # stdout carries the one result line; whatever else a library prints there goes to stderr
     if a.selftest_launcher:
         return launcher_selftest(a, rank, world)
     if a.emulate_world and (world > 1 or a.emulate_world < 1):
@@ -1335,7 +1358,7 @@ def main():
                                                                     a.cpu_seconds / 2, bool(M), orbfe.MP_DTYPE, a.cpu_threads)
                 out["cpu_baseline"]["all_cores"] = {"value": fps_all, "unit": "frames/s", "cores": used,
                                                     "sample": "%d frames over %d host threads, %.1f s wall" % (n_all, used, wall)}
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     if not all_ok:
