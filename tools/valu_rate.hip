@@ -96,6 +96,40 @@ DEFINE_KERNEL(add_sdwa_b, "v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UN
 DEFINE_KERNEL(and_sdwa, "v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
 DEFINE_KERNEL(sub_sdwa16, "v_sub_u16_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0")
 
+// round 5: the opcodes of fast_blur_kernel's emitted ISA that tools/isa_mix.py still priced by assumption
+DEFINE_KERNEL(max_i16, "v_max_i16 %0, %1, %0")
+DEFINE_KERNEL(cndmask_e64, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+DEFINE_KERNEL(lshlrev_b16, "v_lshlrev_b16 %0, 3, %0")
+DEFINE_KERNEL(lshrrev_b16, "v_lshrrev_b16 %0, 3, %0")
+DEFINE_KERNEL(mul_lo_u16, "v_mul_lo_u16 %0, %1, %0")
+DEFINE_KERNEL(readfirstlane, "v_readfirstlane_b32 s20, %0")
+DEFINE_KERNEL(cmp_lt_i16, "v_cmp_lt_i16 vcc, %1, %0")
+DEFINE_KERNEL(cmp_i16_e64, "v_cmp_lt_i16_e64 s[20:21], %1, %0")
+DEFINE_KERNEL(mbcnt_hi, "v_mbcnt_hi_u32_b32 %0, %1, %0")
+
+// 64-bit forms: accumulators are register pairs
+#define DEFINE_KERNEL64(NAME, ASM)                                                                                \
+    __global__ __launch_bounds__(256) void k_##NAME(unsigned* out, int iters, unsigned seed)                     \
+    {                                                                                                            \
+        unsigned long long a[8];                                                                                 \
+        const unsigned b = threadIdx.x * 2654435761u + seed, c = b ^ 0x5bd1e995u;                                \
+        const unsigned long long b64 = ((unsigned long long)b << 32) | c;                                        \
+        for (int i = 0; i < 8; i++) a[i] = b64 + i * 977u;                                                       \
+        for (int it = 0; it < iters; it++) {                                                                     \
+            _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                      \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c), "v"(b64) : "vcc", "s20", "s21");   \
+            }                                                                                                    \
+        }                                                                                                        \
+        unsigned long long r = 0;                                                                                \
+        for (int i = 0; i < 8; i++) r ^= a[i];                                                                   \
+        if (r == 0x12345u) out[threadIdx.x] = (unsigned)r;                                                       \
+    }
+DEFINE_KERNEL64(lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %3")
+DEFINE_KERNEL64(mad_u64_u32, "v_mad_u64_u32 %0, s[20:21], %1, %2, %0")
+DEFINE_KERNEL64(mad_i64_i32, "v_mad_i64_i32 %0, s[20:21], %1, %2, %0")
+DEFINE_KERNEL64(mov_b64, "v_mov_b64 %0, %3")
+DEFINE_KERNEL64(lshlrev_b64, "v_lshlrev_b64 %0, 3, %0")
+
 // round 3b: the same fast-group instructions with THREE DISTINCT registers (dst, src0, src1 all different, sources rotating) --
 // is the fast rate a property of the opcode or of the operand pattern of the chains above (src1 == dst, src0 constant)?
 #define DEFINE_KERNEL3(NAME, ASM)                                                                                \
@@ -264,6 +298,10 @@ int main()
     RUN(min_i16, 64) RUN(lshl_add, 64) RUN(add_lshl, 64) RUN(xad, 64) RUN(mad_i24, 64) RUN(mul_u24, 64) RUN(add_f32, 64) RUN(mul_f32, 64)
     RUN(cvt_u32_f32, 64) RUN(pk_lshl_u16, 64) RUN(pk_mul_u16, 64) RUN(sat_pk_u8, 64) RUN(cvt_pk_u8, 64) RUN(readlane, 64)
     RUN(bpermute_free, 64) RUN(add_sdwa_b, 64) RUN(and_sdwa, 64) RUN(sub_sdwa16, 64)
+    printf("-- round 5: the rest of fast_blur_kernel's opcodes --\n");
+    RUN(max_i16, 64) RUN(cndmask_e64, 64) RUN(lshlrev_b16, 64) RUN(lshrrev_b16, 64) RUN(mul_lo_u16, 64) RUN(readfirstlane, 64)
+    RUN(cmp_lt_i16, 64) RUN(cmp_i16_e64, 64) RUN(mbcnt_hi, 64)
+    RUN(lshl_add_u64, 64) RUN(mad_u64_u32, 64) RUN(mad_i64_i32, 64) RUN(mov_b64, 64) RUN(lshlrev_b64, 64)
     printf("-- round 3b: three distinct registers per instruction --\n");
 #define RUN3(NAME) printf("%-18s %.2f\n", #NAME "_3reg", run(k3_##NAME, d, iters, 64));
     RUN3(min_u16) RUN3(xor_b32) RUN3(add_u32) RUN3(sub_u16) RUN3(pk_min_u16) RUN3(min_u32)
