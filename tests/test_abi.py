@@ -56,6 +56,13 @@ def test_create_rejects_bad_arguments(built):
     bad = orbfe.Params(1000, 16000, 1.2, 8, 5, 7, 752, 480, 0, 1)  # iniTh < minTh: unsupported by the fused pass
     assert L.orbfe_create(C.byref(bad), C.byref(h)) == 2
     assert L.orbfe_max_keypoints(None) == 0 and L.orbfe_get_levels(None) == 0
+    # the round-5 entry points refuse a missing handle / object with a status code before anything touches the GPU
+    assert L.orbfe_track_initialization(None, None, 752, None, None, 40, 0.45, 1, None, None, None, None, None, None) == 1
+    assert L.orbfe_init_frame_create(None, 0, None, None, C.byref(h)) == 1 and L.orbfe_init_frame_size(None) == 0
+    L.orbfe_init_frame_destroy(None)
+    assert L.orbfe_keyframe_set_grid(None, None, 64, 48, 0.0, 0.0, 0.1, 0.1, None, None) == 1
+    assert L.orbfe_fuse_search_keyframe(None, None, None, 0, None, None, 3.0, None, None) == 1
+    assert L.orbfe_set_stream_priority(None, 1) == 1 and L.orbfe_debug_clock_probe(None, 20, None, None) == 1
 
 
 def test_shipped_library_reads_no_environment_and_host_only_entries_work(built):
