@@ -96,6 +96,23 @@ def test_unaligned_device_input(built, pitch_extra, base_off):
             assert np.array_equal(ex.pyramid_level(l, True, frame=b), ref.level_image(l, True)), (b, l)
 
 
+def test_square_frame_at_the_size_limit_through_the_chained_pyramid(built):
+    """4095 x 4095, one frame per call: the single-frame path builds two pyramid levels per launch (launch_pyramid_chain), and
+    levels 1 + 2 of this frame are 19.7 M pixels = 77 k blocks of 256 -- more than the 65535 a grid's y dimension takes (the
+    pixel index travels on grid.x since round 5).  Every level image and the keypoints against the oracle."""
+    import orbfe
+    W = H = 4095
+    args = (3000, 400000, 1.2, 4, 20, 7, W, H)
+    ex = orbfe.ORBextractor(*args, device=0, max_batch=1)
+    ref = O.Extractor(*args)
+    im = synth.frame(W, H, 5)
+    kp, desc = ex.extractFeatures(im)
+    kp_r, desc_r, _ = ref.extract(im)
+    assert len(kp) == len(kp_r) > 2500 and kp.tobytes() == kp_r.tobytes() and np.array_equal(desc, desc_r)
+    for l in range(1, 4):
+        assert np.array_equal(ex.pyramid_level(l, False), ref.level_image(l, False)), l
+
+
 @pytest.mark.parametrize("W,H", [(3840, 2160), (4095, 2303)])
 def test_frames_at_the_size_limit(built, W, H):
     """4K frames and the largest level the packed candidate words allow (x, y < 4096): 130 x 72 FAST
