@@ -1033,7 +1033,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     # everything (our kernels, torch copies, the RCCL gather) is ordered on ONE explicit stream; the
     # default stream's handle is 0, which the C ABI reads as "use the handle's own stream"
-    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    # BENCH_S1_PRIORITY: experiment knob (-1 = the extraction stream at high priority, so that the matcher's kernels on the second
+    # stream are dispatched only into slots the extraction kernels leave free)
+    torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ.get("BENCH_S1_PRIORITY", "0"))))
     dist = None
     if world > 1 or a.force_gather:
         import torch.distributed as dist_
